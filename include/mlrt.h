@@ -1,0 +1,209 @@
+/* include/mlrt.h - C ABI of libmlrt_hip.so: the MI355X (gfx950) render path.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference CPU path tracer
+ * (mu-lambda-raytracer): the call pair
+ *     Renderer::new_with_rng(camera, world, background, params, RecursiveRayTracer{max_depth}, rngator)
+ *         (/root/reference/src/main.rs:147-155, signature src/raytrace.rs:151-160)
+ *     rt.render(logger) -> Vec<Vec<RGB>>        (src/main.rs:157, src/raytrace.rs:172-186)
+ * The reference has no FFI surface of its own (the seams are Rust traits and `world` is an opaque
+ * Box<dyn Hittable>, src/worlds.rs:18), so the host side passes a FLATTENED, plain-old-data scene description
+ * (the same objects the world builders of src/worlds.rs create, in the same order) plus the 7 Camera fields
+ * (src/camera.rs:3-12) and RenderingParams (src/raytrace.rs:50-55).  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a maintainer would add at src/main.rs:157.
+ *
+ * Conventions (mirroring the seam): every pointer is owned by the caller before and after a call; the
+ * library copies what it needs to the device.  Errors: non-zero return + mlrt_last_error() (thread-local
+ * message); no exception crosses the ABI.  All geometry is f64 at the ABI, as in the reference (src/vec.rs:5-8).
+ * There is NO CPU fallback: every compute entry point fails with MLRT_ERR_NO_DEVICE when no HIP device exists.
+ */
+#ifndef MLRT_H
+#define MLRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLRT_VERSION_MAJOR 0
+#define MLRT_VERSION_MINOR 1
+
+enum {
+    MLRT_OK = 0,
+    MLRT_ERR_INVALID = 1,   /* bad argument / malformed scene (the reference would panic) */
+    MLRT_ERR_NO_DEVICE = 2, /* no HIP device: the product path never falls back to the CPU */
+    MLRT_ERR_HIP = 3,       /* a HIP runtime call failed */
+    MLRT_ERR_UNSUPPORTED = 4
+};
+
+/* src/materials.rs, src/volumes.rs:67-83 */
+enum { MLRT_MAT_LAMBERTIAN = 0, MLRT_MAT_METAL = 1, MLRT_MAT_DIELECTRIC = 2, MLRT_MAT_DIFFUSE_LIGHT = 3, MLRT_MAT_ISOTROPIC = 4 };
+/* src/textures.rs, src/image_texture.rs */
+enum { MLRT_TEX_SOLID = 0, MLRT_TEX_IMAGE = 1, MLRT_TEX_NOISE = 2, MLRT_TEX_CHECKER = 3 };
+/* src/shapes.rs: Sphere, Block (box), XY/XZ/YZRect */
+enum { MLRT_PRIM_SPHERE = 0, MLRT_PRIM_BOX = 1, MLRT_PRIM_RECT = 2 };
+/* entries of the top-level HittableList (src/hittable.rs:37-69), in reference order */
+enum { MLRT_OBJ_PRIM = 0, MLRT_OBJ_BVH = 1, MLRT_OBJ_MEDIUM = 2 };
+/* src/raytrace.rs:8-48 */
+enum { MLRT_BG_BLACK = 0, MLRT_BG_GRADIENT = 1 };
+/* arithmetic of the device path */
+enum { MLRT_PRECISION_FP32 = 0, /* fast path: f32 rays/boxes, f64 island for the sphere quadratic */
+       MLRT_PRECISION_FP64 = 1  /* parity path: everything f64, reference operation order */ };
+
+typedef struct mlrt_material {
+    int32_t kind;     /* MLRT_MAT_* */
+    int32_t texture;  /* Lambertian albedo / DiffuseLight emit / Isotropic albedo: index into textures; else -1 */
+    double albedo[3]; /* Metal albedo (materials.rs:37-40) */
+    double param;     /* Metal fuzz | Dielectric index_of_refraction */
+} mlrt_material;
+
+typedef struct mlrt_texture {
+    int32_t kind;    /* MLRT_TEX_* */
+    int32_t index;   /* IMAGE: index into images; NOISE: index into perlins; CHECKER: odd texture */
+    int32_t index2;  /* CHECKER: even texture */
+    int32_t _pad;
+    double color[3]; /* SOLID (textures.rs:8-26) */
+    double scale;    /* NOISE (textures.rs:151-167) */
+} mlrt_texture;
+
+typedef struct mlrt_image {  /* image_texture.rs: decoded RGB8, row 0 = top */
+    int32_t width, height;
+    const uint8_t* rgb;
+} mlrt_image;
+
+typedef struct mlrt_perlin {  /* textures.rs:51-74: tables as drawn by Perlin::new */
+    const double* ranvec;     /* [1024][3] */
+    const int32_t* perm;      /* [3][1024]: perm_x, perm_y, perm_z */
+} mlrt_perlin;
+
+typedef struct mlrt_sphere {  /* shapes.rs:25-42 */
+    double center[3];
+    double radius;
+    int32_t material;
+    int32_t _pad;
+} mlrt_sphere;
+
+typedef struct mlrt_box {  /* shapes.rs:166-198 Block: six AARects sharing one material */
+    double min[3], max[3];
+    int32_t material;
+    int32_t _pad;
+} mlrt_box;
+
+typedef struct mlrt_rect {  /* aarects.rs:19-43 */
+    int32_t a0, a1;         /* in-plane axes (0=X,1=Y,2=Z); the plane axis is 3-a0-a1 */
+    double a0_v0, a0_v1, a1_v0, a1_v1, plane;
+    int32_t material;
+    int32_t _pad;
+} mlrt_rect;
+
+typedef struct mlrt_prim_ref {
+    int32_t kind;  /* MLRT_PRIM_* */
+    int32_t index; /* into spheres / boxes / rects */
+} mlrt_prim_ref;
+
+/* One inner node of a BHV (bhv.rs:109-112) in the topology the reference's Node::new builds
+ * (random axis, stable sort, median split; bhv.rs:122-145).  A child >= 0 is an inner-node index into
+ * bvh_nodes; a child < 0 is a leaf: ~child indexes prim_refs. */
+typedef struct mlrt_bvh_node {
+    double bounds_min[3], bounds_max[3];
+    int32_t left, right;
+} mlrt_bvh_node;
+
+#define MLRT_BVH_EMPTY INT32_MIN /* BHV over zero shapes: Leaf(Empty), bhv.rs:124 */
+typedef struct mlrt_bvh {
+    int32_t root; /* child encoding as above, or MLRT_BVH_EMPTY */
+    int32_t _pad;
+} mlrt_bvh;
+
+/* Translate(offset, Rotate(axis, angle, x)) (transforms.rs:20-49, 51-148); either part may be absent. */
+typedef struct mlrt_transform {
+    int32_t has_rotate, axis;
+    double sin_theta, cos_theta;
+    int32_t has_translate, _pad;
+    double offset[3];
+} mlrt_transform;
+
+typedef struct mlrt_object {
+    int32_t kind;           /* MLRT_OBJ_* */
+    int32_t bvh;            /* BVH: index into bvhs */
+    mlrt_prim_ref prim;     /* PRIM: the primitive; MEDIUM: the boundary (volumes.rs:7-11) */
+    int32_t transform;      /* -1 or index into transforms */
+    int32_t phase_material; /* MEDIUM: Isotropic material */
+    double neg_inv_density; /* MEDIUM: -1/density (volumes.rs:15) */
+} mlrt_object;
+
+typedef struct mlrt_scene {
+    int32_t n_spheres, n_boxes, n_rects, n_prim_refs, n_bvh_nodes, n_bvhs, n_transforms, n_objects, n_materials, n_textures,
+        n_images, n_perlins;
+    const mlrt_sphere* spheres;
+    const mlrt_box* boxes;
+    const mlrt_rect* rects;
+    const mlrt_prim_ref* prim_refs;
+    const mlrt_bvh_node* bvh_nodes;
+    const mlrt_bvh* bvhs;
+    const mlrt_transform* transforms;
+    const mlrt_object* objects; /* the world: hit like a HittableList, in this order */
+    const mlrt_material* materials;
+    const mlrt_texture* textures;
+    const mlrt_image* images;
+    const mlrt_perlin* perlins;
+} mlrt_scene;
+
+typedef struct mlrt_camera { /* the private fields of src/camera.rs:3-12, as Camera::new computes them */
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    double lens_radius;
+} mlrt_camera;
+
+typedef struct mlrt_params {
+    int32_t image_width, image_height, samples_per_pixel; /* RenderingParams, raytrace.rs:50-55 */
+    int32_t max_depth;                                    /* RecursiveRayTracer, raytrace.rs:74-76 */
+    uint64_t seed;                                        /* SeedableRngator, rngator.rs:17-31 */
+    int32_t background_kind;                              /* MLRT_BG_* */
+    int32_t _pad;
+    double background_top[3], background_bottom[3]; /* GradientBackground, raytrace.rs:12-35 */
+} mlrt_params;
+
+/* Called on the calling thread after each finished band of rows (coarser than the reference's per-row
+ * logger, raytrace.rs:182; main.rs:157-173 only derives a throttled percentage from it). */
+typedef void (*mlrt_progress_fn)(int32_t rows_done, int32_t rows_total, void* user);
+
+typedef struct mlrt_context mlrt_context;
+
+void mlrt_version(int32_t* major, int32_t* minor);
+const char* mlrt_last_error(void);
+int32_t mlrt_device_count(void);
+
+/* Replaces Renderer::new_with_rng: validates the scene, packs it into the device layout (threaded BVH,
+ * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*. */
+int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out);
+void mlrt_context_destroy(mlrt_context* ctx);
+
+/* Replaces Renderer::render.  Renders the rows listed in `rows` (row j = 0 is the BOTTOM row, quirk Q13;
+ * rows == NULL means all rows 0..H-1) into rgb_out, a caller-allocated host array [n_rows][W][3] of int32 in
+ * 0..255 - exactly Vec<Vec<(i32,i32,i32)>> flattened.  Blocks until done. */
+int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* rows,
+                            int32_t n_rows, int32_t* rgb_out, mlrt_progress_fn progress, void* user);
+
+/* Asynchronous device-resident form used for benchmarking and multi-GPU runs: `d_rows` (may be NULL = all
+ * rows) and `d_rgb_out` [n_rows][W][3] int32 are DEVICE pointers on the context's device; `d_accum_out` is an
+ * optional device array [n_rows][W][3] of f64 colour sums (NULL to skip).  The kernel is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = default stream) and the call returns without synchronising. */
+int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* d_rows,
+                                   int32_t n_rows, int32_t* d_rgb_out, double* d_accum_out, void* hip_stream);
+
+/* Time of the most recent render kernel of this context in milliseconds, measured with HIP events on the
+ * launch stream (synchronises on the stop event). Negative if nothing was launched. */
+double mlrt_context_last_kernel_ms(mlrt_context* ctx);
+
+/* Introspection for tests and DESIGN.md: bytes of the packed device scene, whether it is staged in LDS,
+ * threads per workgroup, workgroups launched. out[4]. */
+int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]);
+
+/* One-shot drop-in for main.rs:147-157: create + render all rows + destroy. */
+int32_t mlrt_render(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision,
+                    int32_t* rgb_out, mlrt_progress_fn progress, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLRT_H */

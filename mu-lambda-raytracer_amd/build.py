@@ -1,0 +1,73 @@
+"""Build libmlrt_hip.so (HIP kernels for gfx950 + C ABI + host mirror) and the `mlrt` CLI, in-tree.
+
+    python mu-lambda-raytracer_amd/build.py [--force]
+
+hipcc cross-compiles gfx950 without a GPU.  Outputs: mu-lambda-raytracer_amd/lib/libmlrt_hip.so and
+mu-lambda-raytracer_amd/bin/mlrt (git-ignored, shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_DIR = os.path.join(HERE, "lib")
+BIN_DIR = os.path.join(HERE, "bin")
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(LIB_DIR, "libmlrt_hip.so")
+CLI = os.path.join(BIN_DIR, "mlrt")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+BLOCK = os.environ.get("MLRT_BLOCK", "512")
+
+COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(ROOT, "include")]
+KERNEL = os.path.join(HERE, "csrc", "mlrt_kernel.hip")
+UNITS = [
+    # (object, source, extra flags)
+    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-ffp-contract=fast"]),
+    # parity build: no FMA contraction, so every rounding sits where the reference (and the oracle) has it
+    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=256", "-ffp-contract=off"]),
+    ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
+    ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),
+    ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),
+]
+HEADERS = [os.path.join(ROOT, "include", "mlrt.h"), os.path.join(ROOT, "include", "mlrt_host.h"), os.path.join(HERE, "csrc", "mlrt_device.hpp"),
+           os.path.join(HERE, "host", "host_internal.hpp"), os.path.join(HERE, "host", "pcg64.hpp"), os.path.abspath(__file__)]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose_resources=False):
+    for d in (LIB_DIR, BIN_DIR, OBJ_DIR):
+        os.makedirs(d, exist_ok=True)
+    objs = []
+    for obj, src, extra in UNITS:
+        out = os.path.join(OBJ_DIR, obj)
+        objs.append(out)
+        if force or _stale(out, [src] + HEADERS):
+            cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", out]
+            if verbose_resources and src == KERNEL:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            _run(cmd)
+    if force or _stale(LIB, objs):
+        _run([HIPCC, "-shared", "-fPIC", "-o", LIB] + objs)
+    main_src = os.path.join(HERE, "host", "main.cpp")
+    if force or _stale(CLI, [main_src, LIB] + HEADERS):
+        _run([HIPCC] + COMMON + ["-ffp-contract=off", main_src, "-o", CLI, "-L", LIB_DIR, "-lmlrt_hip", "-Wl,-rpath,$ORIGIN/../lib"])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)
+    print("built", LIB, "and", CLI)

@@ -1,0 +1,496 @@
+// csrc/mlrt_api.cpp - the C ABI of include/mlrt.h: scene validation, packing into the device layout
+// (threaded BVH blob, see mlrt_device.hpp), upload to HBM and kernel launch.  Host code only; the kernels
+// live in mlrt_kernel.hip (built twice: f32 and f64).  There is no CPU render path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mlrt.h"
+#include "mlrt_device.hpp"
+
+extern "C" {
+int mlrt_launch_f32(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
+int mlrt_launch_f64(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
+int mlrt_block_threads_f32(void);
+int mlrt_block_threads_f64(void);
+int mlrt_acc_bytes_per_wave_f32(void);
+int mlrt_acc_bytes_per_wave_f64(void);
+int mlrt_occupancy_f32(int lds_scene, size_t dyn_lds);
+int mlrt_occupancy_f64(int lds_scene, size_t dyn_lds);
+}
+
+namespace mlrt {
+void set_last_error(const std::string& msg);  // host/host_api.cpp (same library)
+const char* last_error_cstr();
+
+namespace {
+
+struct Fail {
+    int32_t code;
+    std::string msg;
+};
+#define MLRT_REQUIRE(cond, text) \
+    do { if (!(cond)) throw Fail{MLRT_ERR_INVALID, std::string(text)}; } while (0)
+#define MLRT_HIP(call) \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) throw Fail{MLRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)}; } while (0)
+
+template <typename R>
+struct Packed {
+    std::vector<DNode<R>> nodes;
+    std::vector<DObject<R>> objects;
+    std::vector<DMaterial<R>> materials;
+    std::vector<DTexture<R>> textures;
+    std::vector<R> perlin_vec;
+    std::vector<uint16_t> perlin_perm;
+    std::vector<unsigned char> blob;
+    int32_t off_nodes = 0, off_objects = 0, off_materials = 0, off_textures = 0, off_perlin_vec = 0, off_perlin_perm = 0;
+};
+
+void validate(const mlrt_scene& s) {
+    MLRT_REQUIRE(s.n_objects > 0 && s.objects, "scene has no objects");
+    MLRT_REQUIRE(s.n_spheres >= 0 && s.n_boxes >= 0 && s.n_rects >= 0 && s.n_prim_refs >= 0 && s.n_bvh_nodes >= 0 && s.n_bvhs >= 0 &&
+                     s.n_transforms >= 0 && s.n_materials >= 0 && s.n_textures >= 0 && s.n_images >= 0 && s.n_perlins >= 0,
+                 "negative element count");
+    auto mat_ok = [&](int32_t m) { return m >= 0 && m < s.n_materials; };
+    for (int i = 0; i < s.n_spheres; i++) MLRT_REQUIRE(mat_ok(s.spheres[i].material), "sphere material out of range");
+    for (int i = 0; i < s.n_boxes; i++) MLRT_REQUIRE(mat_ok(s.boxes[i].material), "box material out of range");
+    for (int i = 0; i < s.n_rects; i++) {
+        const mlrt_rect& r = s.rects[i];
+        MLRT_REQUIRE(mat_ok(r.material), "rect material out of range");
+        // aarects.rs:9-17 other(): only (X,Y), (X,Z), (Y,Z) are legal, anything else panics
+        MLRT_REQUIRE((r.a0 == 0 && r.a1 == 1) || (r.a0 == 0 && r.a1 == 2) || (r.a0 == 1 && r.a1 == 2), "rect axes must be (0,1), (0,2) or (1,2)");
+    }
+    auto prim_ok = [&](const mlrt_prim_ref& p) {
+        if (p.kind == MLRT_PRIM_SPHERE) return p.index >= 0 && p.index < s.n_spheres;
+        if (p.kind == MLRT_PRIM_BOX) return p.index >= 0 && p.index < s.n_boxes;
+        if (p.kind == MLRT_PRIM_RECT) return p.index >= 0 && p.index < s.n_rects;
+        return false;
+    };
+    for (int i = 0; i < s.n_prim_refs; i++) MLRT_REQUIRE(prim_ok(s.prim_refs[i]), "prim_ref out of range");
+    auto child_ok = [&](int32_t c) { return c >= 0 ? c < s.n_bvh_nodes : (~c) < s.n_prim_refs; };
+    for (int i = 0; i < s.n_bvh_nodes; i++) MLRT_REQUIRE(child_ok(s.bvh_nodes[i].left) && child_ok(s.bvh_nodes[i].right), "bvh child out of range");
+    for (int i = 0; i < s.n_bvhs; i++) MLRT_REQUIRE(s.bvhs[i].root == MLRT_BVH_EMPTY || child_ok(s.bvhs[i].root), "bvh root out of range");
+    for (int i = 0; i < s.n_transforms; i++) MLRT_REQUIRE(!s.transforms[i].has_rotate || (s.transforms[i].axis >= 0 && s.transforms[i].axis <= 2), "rotation axis out of range");
+    for (int i = 0; i < s.n_textures; i++) {
+        const mlrt_texture& t = s.textures[i];
+        if (t.kind == MLRT_TEX_IMAGE) MLRT_REQUIRE(t.index >= 0 && t.index < s.n_images, "image texture index out of range");
+        else if (t.kind == MLRT_TEX_NOISE) MLRT_REQUIRE(t.index >= 0 && t.index < s.n_perlins, "noise texture index out of range");
+        else if (t.kind == MLRT_TEX_CHECKER) MLRT_REQUIRE(t.index >= 0 && t.index < s.n_textures && t.index2 >= 0 && t.index2 < s.n_textures, "checker texture index out of range");
+        else MLRT_REQUIRE(t.kind == MLRT_TEX_SOLID, "unknown texture kind");
+    }
+    for (int i = 0; i < s.n_images; i++) MLRT_REQUIRE(s.images[i].width > 0 && s.images[i].height > 0 && s.images[i].rgb, "empty image");
+    for (int i = 0; i < s.n_perlins; i++) MLRT_REQUIRE(s.perlins[i].ranvec && s.perlins[i].perm, "perlin table is NULL");
+    for (int i = 0; i < s.n_materials; i++) {
+        const mlrt_material& m = s.materials[i];
+        MLRT_REQUIRE(m.kind >= MLRT_MAT_LAMBERTIAN && m.kind <= MLRT_MAT_ISOTROPIC, "unknown material kind");
+        if (m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC)
+            MLRT_REQUIRE(m.texture >= 0 && m.texture < s.n_textures, "material texture out of range");
+    }
+    for (int i = 0; i < s.n_objects; i++) {
+        const mlrt_object& o = s.objects[i];
+        MLRT_REQUIRE(o.transform >= -1 && o.transform < s.n_transforms, "object transform out of range");
+        if (o.kind == MLRT_OBJ_BVH) MLRT_REQUIRE(o.bvh >= 0 && o.bvh < s.n_bvhs, "object bvh out of range");
+        else if (o.kind == MLRT_OBJ_PRIM) MLRT_REQUIRE(prim_ok(o.prim), "object primitive out of range");
+        else if (o.kind == MLRT_OBJ_MEDIUM) MLRT_REQUIRE(prim_ok(o.prim) && mat_ok(o.phase_material), "medium boundary/material out of range");
+        else MLRT_REQUIRE(false, "unknown object kind");
+    }
+}
+
+bool texture_needs_uv(const mlrt_scene& s, int32_t tex, int depth) {
+    if (tex < 0 || depth > 8) return false;
+    const mlrt_texture& t = s.textures[tex];
+    if (t.kind == MLRT_TEX_IMAGE) return true;
+    if (t.kind == MLRT_TEX_CHECKER) return texture_needs_uv(s, t.index, depth + 1) || texture_needs_uv(s, t.index2, depth + 1);
+    return false;
+}
+
+template <typename R>
+DNode<R> leaf_node(const mlrt_scene& s, const mlrt_prim_ref& p) {
+    DNode<R> n{};
+    if (p.kind == MLRT_PRIM_SPHERE) {
+        const mlrt_sphere& sp = s.spheres[p.index];
+        n.v[0] = (R)sp.center[0]; n.v[1] = (R)sp.center[1]; n.v[2] = (R)sp.center[2]; n.v[3] = (R)sp.radius;
+        n.link = sp.material; n.tag = TAG_SPHERE;
+    } else if (p.kind == MLRT_PRIM_BOX) {
+        const mlrt_box& b = s.boxes[p.index];
+        for (int k = 0; k < 3; k++) { n.v[k] = (R)b.min[k]; n.v[3 + k] = (R)b.max[k]; }
+        n.link = b.material; n.tag = TAG_BOX;
+    } else {
+        const mlrt_rect& r = s.rects[p.index];
+        n.v[0] = (R)r.a0_v0; n.v[1] = (R)r.a0_v1; n.v[2] = (R)r.a1_v0; n.v[3] = (R)r.a1_v1; n.v[4] = (R)r.plane;
+        n.link = r.material;
+        n.tag = TAG_RECT | (r.a0 << 4) | (r.a1 << 6) | ((3 - r.a0 - r.a1) << 8);
+    }
+    return n;
+}
+
+// Depth-first emission with skip links.  `budget` guards against cyclic child references.
+template <typename R>
+void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out, int& budget) {
+    MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
+    if (child < 0) { out.push_back(leaf_node<R>(s, s.prim_refs[~child])); return; }
+    const mlrt_bvh_node& src = s.bvh_nodes[child];
+    const size_t me = out.size();
+    DNode<R> n{};
+    for (int k = 0; k < 3; k++) { n.v[k] = (R)src.bounds_min[k]; n.v[3 + k] = (R)src.bounds_max[k]; }
+    n.tag = TAG_INNER;
+    out.push_back(n);
+    emit_subtree<R>(s, src.left, out, budget);
+    emit_subtree<R>(s, src.right, out, budget);
+    out[me].link = (int32_t)out.size();
+}
+
+template <typename T>
+int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
+    while (blob.size() % 16) blob.push_back(0);
+    const int32_t off = (int32_t)blob.size();
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(v.data());
+    blob.insert(blob.end(), p, p + v.size() * sizeof(T));
+    return off;
+}
+
+template <typename R>
+Packed<R> pack(const mlrt_scene& s) {
+    Packed<R> P;
+    for (int i = 0; i < s.n_objects; i++) {
+        const mlrt_object& src = s.objects[i];
+        DObject<R> o{};
+        o.kind = src.kind;
+        o.node_begin = (int32_t)P.nodes.size();
+        if (src.kind == MLRT_OBJ_BVH) {
+            const int32_t root = s.bvhs[src.bvh].root;
+            if (root == MLRT_BVH_EMPTY) {
+                DNode<R> e{};
+                e.tag = TAG_EMPTY;
+                P.nodes.push_back(e);
+            } else {
+                int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
+                emit_subtree<R>(s, root, P.nodes, budget);
+            }
+        } else {
+            P.nodes.push_back(leaf_node<R>(s, src.prim));
+        }
+        o.node_end = (int32_t)P.nodes.size();
+        o.sin_t = 0; o.cos_t = 1;
+        if (src.transform >= 0) {
+            const mlrt_transform& t = s.transforms[src.transform];
+            if (t.has_translate) { o.xform |= XF_TRANSLATE; for (int k = 0; k < 3; k++) o.off[k] = (R)t.offset[k]; }
+            if (t.has_rotate) { o.xform |= XF_ROTATE | (t.axis << 4); o.sin_t = (R)t.sin_theta; o.cos_t = (R)t.cos_theta; }
+        }
+        o.neg_inv_density = (R)src.neg_inv_density;
+        o.phase_mat = src.phase_material;
+        P.objects.push_back(o);
+    }
+    for (int i = 0; i < s.n_materials; i++) {
+        const mlrt_material& m = s.materials[i];
+        DMaterial<R> d{};
+        d.kind = m.kind | (texture_needs_uv(s, m.texture, 0) ? MATFLAG_NEEDS_UV : 0);
+        d.tex = m.texture;
+        for (int k = 0; k < 3; k++) d.albedo[k] = (R)m.albedo[k];
+        d.param = (R)m.param;
+        P.materials.push_back(d);
+    }
+    for (int i = 0; i < s.n_textures; i++) {
+        const mlrt_texture& t = s.textures[i];
+        DTexture<R> d{};
+        d.kind = t.kind; d.a = t.index; d.b = t.index2;
+        for (int k = 0; k < 3; k++) d.color[k] = (R)t.color[k];
+        d.scale = (R)t.scale;
+        P.textures.push_back(d);
+    }
+    for (int i = 0; i < s.n_perlins; i++) {
+        for (int k = 0; k < 3072; k++) P.perlin_vec.push_back((R)s.perlins[i].ranvec[k]);
+        for (int k = 0; k < 3072; k++) {
+            const int32_t v = s.perlins[i].perm[k];
+            MLRT_REQUIRE(v >= 0 && v < 1024, "perlin permutation entry out of range");
+            P.perlin_perm.push_back((uint16_t)v);
+        }
+    }
+    P.off_nodes = append(P.blob, P.nodes);
+    P.off_objects = append(P.blob, P.objects);
+    P.off_materials = append(P.blob, P.materials);
+    P.off_textures = append(P.blob, P.textures);
+    P.off_perlin_vec = append(P.blob, P.perlin_vec);
+    P.off_perlin_perm = append(P.blob, P.perlin_perm);
+    while (P.blob.size() % 16) P.blob.push_back(0);
+    return P;
+}
+
+}  // namespace
+}  // namespace mlrt
+
+using namespace mlrt;
+
+struct mlrt_context {
+    int32_t device = 0, precision = MLRT_PRECISION_FP32;
+    int32_t n_cus = 0;
+    unsigned char* d_blob = nullptr;
+    int32_t blob_bytes = 0;
+    int32_t off[6] = {0, 0, 0, 0, 0, 0};
+    int32_t n_objects = 0;
+    std::vector<unsigned char*> d_image_pixels;
+    DImage* d_images = nullptr;
+    unsigned int* d_tile_counter = nullptr;
+    bool lds_scene = false;
+    size_t dyn_lds = 0;
+    int32_t block_threads = 0, blocks_per_cu = 1, last_grid = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+void destroy(mlrt_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_blob) (void)hipFree(c->d_blob);
+    for (unsigned char* p : c->d_image_pixels) (void)hipFree(p);
+    if (c->d_images) (void)hipFree(c->d_images);
+    if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    delete c;
+}
+
+template <typename R>
+void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb,
+                 double* d_accum, KParams<R>& K) {
+    K.blob = c->d_blob; K.blob_bytes = c->blob_bytes;
+    K.off_nodes = c->off[0]; K.off_objects = c->off[1]; K.off_materials = c->off[2]; K.off_textures = c->off[3];
+    K.off_perlin_vec = c->off[4]; K.off_perlin_perm = c->off[5];
+    K.n_objects = c->n_objects;
+    K.images = c->d_images;
+    for (int k = 0; k < 3; k++) {
+        K.cam_origin[k] = (R)cam->origin[k]; K.cam_llc[k] = (R)cam->lower_left_corner[k];
+        K.cam_horizontal[k] = (R)cam->horizontal[k]; K.cam_vertical[k] = (R)cam->vertical[k];
+        K.cam_u[k] = (R)cam->u[k]; K.cam_v[k] = (R)cam->v[k];
+        K.bg_top[k] = (R)p->background_top[k]; K.bg_bottom[k] = (R)p->background_bottom[k];
+    }
+    K.lens_radius = (R)cam->lens_radius;
+    K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
+    K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
+    K.bg_kind = p->background_kind;
+    K.rows = d_rows; K.n_rows = n_rows;
+    int pix = 1;
+    while (pix < 64 && (int64_t)pix * p->samples_per_pixel < 4096) pix *= 2;
+    while (pix > 1 && pix > p->image_width) pix /= 2;
+    K.pix_per_tile = pix;
+    K.tiles_per_row = (p->image_width + pix - 1) / pix;
+    K.n_tiles = K.tiles_per_row * n_rows;
+    K.rgb_out = d_rgb; K.accum_out = d_accum;
+    K.tile_counter = c->d_tile_counter;
+}
+
+void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) {
+    MLRT_REQUIRE(cam && p, "camera/params is NULL");
+    MLRT_REQUIRE(p->image_width >= 2 && p->image_height >= 2, "image must be at least 2x2 (u = (i+x)/(W-1), raytrace.rs:191-192)");
+    MLRT_REQUIRE(p->samples_per_pixel >= 1 && p->samples_per_pixel <= (1 << 24), "samples_per_pixel out of range");
+    MLRT_REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
+    MLRT_REQUIRE((int64_t)p->image_width * p->image_height < (int64_t)1 << 31, "image too large for the 32-bit pixel counter of the Philox stream");
+    MLRT_REQUIRE(n_rows >= 0 && n_rows <= p->image_height, "n_rows out of range");
+    MLRT_REQUIRE(p->background_kind == MLRT_BG_BLACK || p->background_kind == MLRT_BG_GRADIENT, "unknown background kind");
+}
+
+void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb, double* d_accum,
+            hipStream_t stream) {
+    if (n_rows == 0) return;
+    MLRT_HIP(hipSetDevice(c->device));
+    MLRT_HIP(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), stream));
+    const int waves_per_block = c->block_threads / 64;
+    int rc;
+    int grid;
+    MLRT_HIP(hipEventRecord(c->ev_start, stream));
+    if (c->precision == MLRT_PRECISION_FP32) {
+        KParams<float> K{};
+        fill_params<float>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
+        grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
+        rc = mlrt_launch_f32(&K, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+    } else {
+        KParams<double> K{};
+        fill_params<double>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
+        grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
+        rc = mlrt_launch_f64(&K, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+    }
+    if (rc != 0) throw Fail{MLRT_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)};
+    MLRT_HIP(hipEventRecord(c->ev_stop, stream));
+    c->last_grid = grid;
+    c->timed = true;
+}
+
+template <typename F>
+int32_t guarded(F&& f) {
+    try {
+        f();
+        return MLRT_OK;
+    } catch (const Fail& e) {
+        mlrt::set_last_error(e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        mlrt::set_last_error(std::string("internal error: ") + e.what());
+        return MLRT_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void mlrt_version(int32_t* major, int32_t* minor) {
+    if (major) *major = MLRT_VERSION_MAJOR;
+    if (minor) *minor = MLRT_VERSION_MINOR;
+}
+const char* mlrt_last_error(void) { return mlrt::last_error_cstr(); }
+int32_t mlrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out) {
+    mlrt_context* c = nullptr;
+    const int32_t rc = guarded([&] {
+        MLRT_REQUIRE(scene && out, "scene/out is NULL");
+        MLRT_REQUIRE(precision == MLRT_PRECISION_FP32 || precision == MLRT_PRECISION_FP64, "unknown precision");
+        *out = nullptr;
+        validate(*scene);
+        const int n_dev = mlrt_device_count();
+        if (n_dev <= 0) throw Fail{MLRT_ERR_NO_DEVICE, "no HIP device is visible: libmlrt_hip has no CPU fallback"};
+        MLRT_REQUIRE(device >= 0 && device < n_dev, "device ordinal out of range");
+        c = new mlrt_context();
+        c->device = device; c->precision = precision;
+        MLRT_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        MLRT_HIP(hipGetDeviceProperties(&prop, device));
+        c->n_cus = prop.multiProcessorCount;
+        std::vector<unsigned char> blob;
+        if (precision == MLRT_PRECISION_FP32) {
+            Packed<float> P = pack<float>(*scene);
+            blob.swap(P.blob);
+            const int32_t o[6] = {P.off_nodes, P.off_objects, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
+            std::memcpy(c->off, o, sizeof o);
+            c->block_threads = mlrt_block_threads_f32();
+        } else {
+            Packed<double> P = pack<double>(*scene);
+            blob.swap(P.blob);
+            const int32_t o[6] = {P.off_nodes, P.off_objects, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
+            std::memcpy(c->off, o, sizeof o);
+            c->block_threads = mlrt_block_threads_f64();
+        }
+        c->blob_bytes = (int32_t)blob.size();
+        c->n_objects = scene->n_objects;
+        MLRT_HIP(hipMalloc(&c->d_blob, blob.size()));
+        MLRT_HIP(hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        std::vector<DImage> images;
+        for (int i = 0; i < scene->n_images; i++) {
+            const size_t bytes = (size_t)scene->images[i].width * scene->images[i].height * 3;
+            unsigned char* d = nullptr;
+            MLRT_HIP(hipMalloc(&d, bytes));
+            c->d_image_pixels.push_back(d);
+            MLRT_HIP(hipMemcpy(d, scene->images[i].rgb, bytes, hipMemcpyHostToDevice));
+            images.push_back(DImage{d, scene->images[i].width, scene->images[i].height});
+        }
+        if (!images.empty()) {
+            MLRT_HIP(hipMalloc(&c->d_images, images.size() * sizeof(DImage)));
+            MLRT_HIP(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DImage), hipMemcpyHostToDevice));
+        }
+        MLRT_HIP(hipMalloc(&c->d_tile_counter, sizeof(unsigned int)));
+        MLRT_HIP(hipEventCreate(&c->ev_start));
+        MLRT_HIP(hipEventCreate(&c->ev_stop));
+        // LDS plan: the f32 blob is staged in LDS when it fits next to the per-wave accumulators
+        const int waves = c->block_threads / 64;
+        const size_t acc = (size_t)waves * (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64());
+        const size_t lds_limit = 160 * 1024;
+        c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit;
+        c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;
+        const int occ = precision == MLRT_PRECISION_FP32 ? mlrt_occupancy_f32(c->lds_scene, c->dyn_lds) : mlrt_occupancy_f64(c->lds_scene, c->dyn_lds);
+        c->blocks_per_cu = occ > 0 ? occ : 1;
+        *out = c;
+    });
+    if (rc != MLRT_OK && c) destroy(c);
+    return rc;
+}
+
+void mlrt_context_destroy(mlrt_context* ctx) { destroy(ctx); }
+
+int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* d_rows, int32_t n_rows,
+                                   int32_t* d_rgb_out, double* d_accum_out, void* hip_stream) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx, "context is NULL");
+        check_params(camera, params, n_rows);
+        MLRT_REQUIRE(d_rgb_out || n_rows == 0, "d_rgb_out is NULL");
+        launch(ctx, camera, params, d_rows, n_rows, d_rgb_out, d_accum_out, static_cast<hipStream_t>(hip_stream));
+    });
+}
+
+int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* rows, int32_t n_rows,
+                            int32_t* rgb_out, mlrt_progress_fn progress, void* user) {
+    int32_t* d_rows = nullptr;
+    int32_t* d_rgb = nullptr;
+    const int32_t rc = guarded([&] {
+        MLRT_REQUIRE(ctx, "context is NULL");
+        MLRT_REQUIRE(camera && params, "camera/params is NULL");
+        if (!rows) n_rows = params->image_height;
+        check_params(camera, params, n_rows);
+        MLRT_REQUIRE(rgb_out || n_rows == 0, "rgb_out is NULL");
+        if (n_rows == 0) return;
+        MLRT_HIP(hipSetDevice(ctx->device));
+        std::vector<int32_t> host_rows((size_t)n_rows);
+        for (int32_t k = 0; k < n_rows; k++) {
+            host_rows[(size_t)k] = rows ? rows[k] : k;
+            MLRT_REQUIRE(host_rows[(size_t)k] >= 0 && host_rows[(size_t)k] < params->image_height, "row index out of range");
+        }
+        const size_t row_elems = (size_t)params->image_width * 3;
+        MLRT_HIP(hipMalloc(&d_rows, (size_t)n_rows * sizeof(int32_t)));
+        MLRT_HIP(hipMalloc(&d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t)));
+        MLRT_HIP(hipMemcpy(d_rows, host_rows.data(), (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+        // with a progress callback the image is rendered in bands so the caller sees rows complete
+        const int32_t bands = progress ? std::min<int32_t>(n_rows, 16) : 1;
+        int32_t done = 0;
+        for (int32_t b = 0; b < bands; b++) {
+            const int32_t begin = (int32_t)((int64_t)n_rows * b / bands), end = (int32_t)((int64_t)n_rows * (b + 1) / bands);
+            if (end == begin) continue;
+            launch(ctx, camera, params, d_rows + begin, end - begin, d_rgb + (size_t)begin * row_elems, nullptr, nullptr);
+            MLRT_HIP(hipStreamSynchronize(nullptr));
+            done = end;
+            if (progress) progress(done, n_rows, user);
+        }
+        MLRT_HIP(hipMemcpy(rgb_out, d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t), hipMemcpyDeviceToHost));
+    });
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_rgb) (void)hipFree(d_rgb);
+    return rc;
+}
+
+double mlrt_context_last_kernel_ms(mlrt_context* ctx) {
+    if (!ctx || !ctx->timed) return -1.0;
+    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]) {
+    if (!ctx || !out) { mlrt::set_last_error("mlrt_context_info: NULL argument"); return MLRT_ERR_INVALID; }
+    out[0] = ctx->blob_bytes;
+    out[1] = ctx->lds_scene ? 1 : 0;
+    out[2] = ctx->block_threads;
+    out[3] = ctx->last_grid > 0 ? ctx->last_grid : (int64_t)ctx->n_cus * ctx->blocks_per_cu;
+    return MLRT_OK;
+}
+
+int32_t mlrt_render(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision, int32_t* rgb_out,
+                    mlrt_progress_fn progress, void* user) {
+    mlrt_context* ctx = nullptr;
+    int32_t rc = mlrt_context_create(scene, 0, precision, &ctx);
+    if (rc != MLRT_OK) return rc;
+    rc = mlrt_context_render(ctx, camera, params, nullptr, 0, rgb_out, progress, user);
+    mlrt_context_destroy(ctx);
+    return rc;
+}
+
+}  // extern "C"

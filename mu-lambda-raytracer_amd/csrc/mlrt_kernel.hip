@@ -1,0 +1,715 @@
+// csrc/mlrt_kernel.hip - the render megakernel for gfx950 (CDNA4, wave64).  Hand-written HIP; no MFMA (branchy
+// intersection arithmetic, not a contraction), no CUDA shims, no second back end.
+//
+// Compiled twice (see mu-lambda-raytracer_amd/build.py):
+//   -DMLRT_REAL=float                        -> fast path:   f32 rays / boxes, f64 island for the sphere quadratic
+//   -DMLRT_REAL=double -ffp-contract=off     -> parity path: f64 throughout, the reference's operation order
+//
+// What it replaces (reference file:line):
+//   Renderer::render / render_line / render_pixel   raytrace.rs:162-198   -> tile queue + per-lane path regeneration
+//   Camera::get_ray                                 camera.rs:40-48       -> gen_camera_ray
+//   RecursiveRayTracer::trace_internal              raytrace.rs:79-102    -> iterative throughput loop
+//   HittableList::hit                               hittable.rs:53-69     -> world_hit (objects in list order)
+//   BHV::hit / Node::hit / AABB::hit                bhv.rs:29-42,147-165  -> threaded (stackless) BVH walk + slab test
+//   Sphere::hit / sphere_uv                         shapes.rs:44-82       -> sphere_hit / sphere_uv
+//   AARect::hit, Block::hit                         aarects.rs:45-64, shapes.rs:172-192 -> rect_hit, box_hit
+//   Translate::hit / Rotate::hit                    transforms.rs:31-42,127-142 -> to_object / from_object
+//   ConstantMedium::hit, Isotropic                  volumes.rs:26-83      -> medium_hit, scatter
+//   Lambertian / Metal / Dielectric / DiffuseLight  materials.rs          -> scatter
+//   SolidColor / Checker / Perlin / Image           textures.rs, image_texture.rs -> texture_value
+//   to_rgb                                          raytrace.rs:59-68     -> fused tile epilogue
+//   Rngator (Pcg64 per row)                         rngator.rs:27-31      -> Philox4x32-10 per (pixel, sample)
+//
+// Execution model: persistent workgroups.  Each workgroup stages the packed scene blob into LDS once
+// (16-byte coalesced loads), then each WAVE pulls tiles (pix_per_tile consecutive pixels of a row) from a global
+// atomic counter.  Inside a tile the pix*spp samples form one queue; a lane whose path has ended takes the next
+// queue entry immediately (__ballot + mbcnt prefix), so lanes stay busy until the tile is exhausted.  Finished
+// samples are added to per-wave pixel accumulators in LDS as 64-bit fixed point (2^-32): integer adds are
+// associative, so the image is bit-identical however samples are distributed over lanes, waves or GPUs.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/mlrt.h"
+#include "mlrt_device.hpp"
+
+#ifndef MLRT_REAL
+#error "compile with -DMLRT_REAL=float or -DMLRT_REAL=double"
+#endif
+#ifndef MLRT_BLOCK
+#define MLRT_BLOCK 512
+#endif
+#define DEV __device__ __forceinline__
+#define MLRT_CAT_(a, b) a##b
+#define MLRT_CAT(a, b) MLRT_CAT_(a, b)
+#ifndef MLRT_SUFFIX
+#error "compile with -DMLRT_SUFFIX=f32 or f64"
+#endif
+#define MLRT_NS MLRT_CAT(mlrt_, MLRT_SUFFIX)
+
+// one namespace per precision build: the two translation units define same-named types of different layout
+namespace MLRT_NS {
+using namespace mlrt;
+
+typedef MLRT_REAL real;
+constexpr bool kFast = sizeof(real) == 4;
+constexpr int kMaxPixPerTile = 64;
+constexpr int kAccBytesPerWave = kMaxPixPerTile * 3 * 8;
+
+// ---------------------------------------------------------------------------------------------- math helpers
+DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV double fast_rcp(double x) { return 1.0 / x; }
+DEV float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEV double sqrt_r(double x) { return sqrt(x); }
+DEV float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DEV double div_r(double a, double b) { return a / b; }
+DEV float min_r(float a, float b) { return fminf(a, b); }
+DEV double min_r(double a, double b) { return fmin(a, b); }
+DEV float max_r(float a, float b) { return fmaxf(a, b); }
+DEV double max_r(double a, double b) { return fmax(a, b); }
+DEV float abs_r(float a) { return fabsf(a); }
+DEV double abs_r(double a) { return fabs(a); }
+DEV float sin_r(float a) { return sinf(a); }
+DEV double sin_r(double a) { return sin(a); }
+DEV float log_r(float a) { return logf(a); }
+DEV double log_r(double a) { return log(a); }
+DEV float floor_r(float a) { return floorf(a); }
+DEV double floor_r(double a) { return floor(a); }
+
+struct V3 {
+    real x, y, z;
+};
+DEV V3 mk(real x, real y, real z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV V3 ld3(const real* p) { return mk(p[0], p[1], p[2]); }
+DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV V3 operator*(V3 a, real s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV V3 operator*(real s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV real length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+DEV real comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+DEV V3 axis_vec(int i, real s) { return mk(i == 0 ? s : (real)0, i == 1 ? s : (real)0, i == 2 ? s : (real)0); }
+// Vec3::unit = self / self.length() (vec.rs:67-69): per-component division in the parity build
+DEV V3 unit(V3 a) {
+    if (kFast) {
+        const real inv = (real)__builtin_amdgcn_rsqf((float)length_squared(a));
+        return a * inv;
+    }
+    const real len = sqrt_r(length_squared(a));
+    return mk(a.x / len, a.y / len, a.z / len);
+}
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+// One stream per (pixel, sample): counter = (draw/4, sample, pixel, 0), key = seed; draw k is word k%4.
+// Identical to PhiloxStream in oracle/oracle_core.hpp, word for word.
+struct Rng {
+    uint32_t pixel, sample, draw;
+    uint32_t b0, b1, b2, b3;
+};
+DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0, uint32_t& o1,
+                       uint32_t& o2, uint32_t& o3) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+struct RngKey {
+    uint32_t k0, k1;
+};
+DEV uint32_t rng_next(Rng& g, RngKey key) {
+    const uint32_t i = g.draw & 3u;
+    if (i == 0) philox4x32_10(key.k0, key.k1, g.draw >> 2, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3);
+    g.draw++;
+    return i == 0 ? g.b0 : (i == 1 ? g.b1 : (i == 2 ? g.b2 : g.b3));
+}
+DEV real rng_uniform(Rng& g, RngKey key) { return (real)(rng_next(g, key) >> 8) * (real)(1.0 / 16777216.0); }
+// rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
+DEV real rng_range(Rng& g, RngKey key, real lo, real hi) { return rng_uniform(g, key) * (hi - lo) + lo; }
+DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {  // vec.rs:23-30
+    for (;;) {
+        const real a = rng_range(g, key, (real)-1, (real)1);
+        const real b = rng_range(g, key, (real)-1, (real)1);
+        const real c = rng_range(g, key, (real)-1, (real)1);
+        const V3 p = mk(a, b, c);
+        if (length_squared(p) < (real)1) return p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- scene view
+struct Scene {
+    const DNode<real>* nodes;
+    const DObject<real>* objects;
+    const DMaterial<real>* materials;
+    const DTexture<real>* textures;
+    const real* perlin_vec;         // [tables][1024][3]
+    const uint16_t* perlin_perm;    // [tables][3][1024]
+    const DImage* images;           // HBM (L2-resident)
+};
+
+struct Ray {
+    V3 o, d;
+    V3 invd;       // fast build only
+    double a;      // |d|^2 for the sphere quadratic
+    double inv_a;  // fast build only
+};
+DEV Ray make_ray(V3 o, V3 d) {
+    Ray r;
+    r.o = o; r.d = d;
+    r.a = (double)d.x * (double)d.x + (double)d.y * (double)d.y + (double)d.z * (double)d.z;
+    if (kFast) {
+        r.invd = mk(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        // reciprocal of |d|^2 to f64 accuracy from an f32 seed + 2 Newton steps (no f64 divide in the hot loop)
+        double x = (double)__builtin_amdgcn_rcpf((float)r.a);
+        x = x * (2.0 - r.a * x);
+        x = x * (2.0 - r.a * x);
+        r.inv_a = x;
+    } else {
+        r.invd = d;
+        r.inv_a = 0.0;
+    }
+    return r;
+}
+
+// AABB::hit, bhv.rs:29-42 (quirk Q5).  Evaluating the three slabs and testing once equals the reference's
+// per-axis early exit because the interval only shrinks.
+DEV bool slab_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax) {
+    real t0, t1;
+    if (kFast) { t0 = (n.v[0] - r.o.x) * r.invd.x; t1 = (n.v[3] - r.o.x) * r.invd.x; }
+    else { t0 = (n.v[0] - r.o.x) / r.d.x; t1 = (n.v[3] - r.o.x) / r.d.x; }
+    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
+    if (kFast) { t0 = (n.v[1] - r.o.y) * r.invd.y; t1 = (n.v[4] - r.o.y) * r.invd.y; }
+    else { t0 = (n.v[1] - r.o.y) / r.d.y; t1 = (n.v[4] - r.o.y) / r.d.y; }
+    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
+    if (kFast) { t0 = (n.v[2] - r.o.z) * r.invd.z; t1 = (n.v[5] - r.o.z) * r.invd.z; }
+    else { t0 = (n.v[2] - r.o.z) / r.d.z; t1 = (n.v[5] - r.o.z) / r.d.z; }
+    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
+    return !(tmax <= tmin);
+}
+
+// Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in BOTH builds: with the radius-1000 ground
+// sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
+// the f32 rate, so the island is cheap; the fast build avoids the f64 divide and square root instructions.
+DEV bool sphere_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out) {
+    const double ocx = (double)r.o.x - (double)n.v[0], ocy = (double)r.o.y - (double)n.v[1], ocz = (double)r.o.z - (double)n.v[2];
+    const double dx = (double)r.d.x, dy = (double)r.d.y, dz = (double)r.d.z;
+    const double radius = (double)n.v[3];
+    const double half_b = ocx * dx + ocy * dy + ocz * dz;
+    const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
+    const double discriminant = half_b * half_b - r.a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd, root;
+    if (kFast) {
+        // sqrt to ~f64 accuracy: f32 rsqrt seed, one Newton step on y = 1/sqrt(x), then s = x*y corrected once
+        if (discriminant == 0.0) {
+            sqrtd = 0.0;
+        } else {
+            double y = (double)__builtin_amdgcn_rsqf((float)discriminant);
+            y = y * (1.5 - 0.5 * discriminant * y * y);
+            double s = discriminant * y;
+            s = s + 0.5 * y * (discriminant - s * s);
+            sqrtd = s;
+        }
+        root = (-half_b - sqrtd) * r.inv_a;
+        if (root < (double)tmin || (double)tmax < root) {
+            root = (-half_b + sqrtd) * r.inv_a;
+            if (root < (double)tmin || (double)tmax < root) return false;
+        }
+    } else {
+        sqrtd = sqrt(discriminant);
+        root = (-half_b - sqrtd) / r.a;
+        if (root < (double)tmin || (double)tmax < root) {
+            root = (-half_b + sqrtd) / r.a;
+            if (root < (double)tmin || (double)tmax < root) return false;
+        }
+    }
+    t_out = (real)root;
+    return true;
+}
+
+// Block::hit = HittableList of six AARects (shapes.rs:172-192, hittable.rs:53-69): the nearest face hit inside
+// [tmin, tmax].  The faces a line can hit inside their rectangles are the slab entry and exit faces, so the six
+// rect tests collapse into one slab evaluation with the same t = (k - o)/d per face.
+DEV bool box_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out, int& axis_out) {
+    real lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const real oa = comp(r.o, a);
+        real t0, t1;
+        if (kFast) { const real ia = comp(r.invd, a); t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
+        else { const real da = comp(r.d, a); t0 = (n.v[a] - oa) / da; t1 = (n.v[3 + a] - oa) / da; }
+        lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
+    }
+    real te = lo[0]; int ae = 0;
+    if (lo[1] > te) { te = lo[1]; ae = 1; }
+    if (lo[2] > te) { te = lo[2]; ae = 2; }
+    real tx = hi[0]; int ax = 0;
+    if (hi[1] < tx) { tx = hi[1]; ax = 1; }
+    if (hi[2] < tx) { tx = hi[2]; ax = 2; }
+    if (te > tx) return false;
+    if (te >= tmin && te <= tmax) { t_out = te; axis_out = ae; return true; }
+    if (tx >= tmin && tx <= tmax) { t_out = tx; axis_out = ax; return true; }
+    return false;
+}
+
+// AARect::hit, aarects.rs:45-64
+DEV bool rect_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out) {
+    const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
+    const real t = kFast ? (n.v[4] - comp(r.o, ap)) * comp(r.invd, ap) : (n.v[4] - comp(r.o, ap)) / comp(r.d, ap);
+    if (t < tmin || t > tmax) return false;
+    const real a0_v = comp(r.o, a0) + t * comp(r.d, a0);
+    const real a1_v = comp(r.o, a1) + t * comp(r.d, a1);
+    if (a0_v < n.v[0] || a0_v > n.v[1] || a1_v < n.v[2] || a1_v > n.v[3]) return false;
+    t_out = t;
+    return true;
+}
+
+DEV bool leaf_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out, int& aux) {
+    const int kind = n.tag & TAG_KIND_MASK;
+    if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
+    if (kind == TAG_BOX) return box_hit(n, r, tmin, tmax, t_out, aux);
+    if (kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
+    return false;  // TAG_EMPTY: shapes.rs:8-23
+}
+
+// Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132)
+DEV V3 rotate_back(const DObject<real>& ob, V3 v) {
+    const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
+    const real v0 = comp(v, a0), v2 = comp(v, a2);
+    const real n0 = ob.cos_t * v0 - ob.sin_t * v2;
+    const real n2 = ob.sin_t * v0 + ob.cos_t * v2;
+    return mk(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+}
+DEV V3 rotate_fwd(const DObject<real>& ob, V3 v) {  // transforms.rs:116-124
+    const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
+    const real v0 = comp(v, a0), v2 = comp(v, a2);
+    const real n0 = ob.cos_t * v0 + ob.sin_t * v2;
+    const real n2 = -ob.sin_t * v0 + ob.cos_t * v2;
+    return mk(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+}
+DEV void to_object(const DObject<real>& ob, V3& o, V3& d) {
+    if (ob.xform & XF_TRANSLATE) o = o - ld3(ob.off);
+    if (ob.xform & XF_ROTATE) { o = rotate_back(ob, o); d = rotate_back(ob, d); }
+}
+
+struct HitRec {
+    real t;
+    int obj;   // index into objects
+    int node;  // leaf node index (PRIM / BVH) or -1 for a medium
+    int aux;   // box: face axis
+};
+
+// HittableList::hit over the top-level objects (hittable.rs:53-69) with closest_so_far shrinking in list order.
+DEV bool world_hit(const Scene& S, int n_objects, V3 o, V3 d, Rng& g, RngKey key, HitRec& rec) {
+    const real t_min = (real)0.001;  // raytrace.rs:90
+    real closest = (real)INFINITY;
+    bool any = false;
+    const Ray world_ray = make_ray(o, d);
+    for (int k = 0; k < n_objects; k++) {
+        const DObject<real> ob = S.objects[k];
+        Ray r = world_ray;
+        if (ob.xform) {
+            V3 oo = o, od = d;
+            to_object(ob, oo, od);
+            r = make_ray(oo, od);
+        }
+        if (ob.kind == MLRT_OBJ_BVH) {
+            // Node::hit, bhv.rs:147-165, as a stackless walk of the threaded tree
+            int node = ob.node_begin;
+            const int end = ob.node_end;
+            while (node < end) {
+                const DNode<real> n = S.nodes[node];
+                if ((n.tag & TAG_KIND_MASK) == TAG_INNER) {
+                    node = slab_hit(n, r, t_min, closest) ? node + 1 : n.link;
+                } else {
+                    real t; int aux = 0;
+                    if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = node; rec.aux = aux; any = true; }
+                    node = node + 1;
+                }
+            }
+        } else if (ob.kind == MLRT_OBJ_PRIM) {
+            const DNode<real> n = S.nodes[ob.node_begin];
+            real t; int aux = 0;
+            if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = ob.node_begin; rec.aux = aux; any = true; }
+        } else {
+            // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
+            const DNode<real> n = S.nodes[ob.node_begin];
+            real t1, t2; int aux = 0;
+            if (leaf_hit(n, r, (real)-INFINITY, (real)INFINITY, t1, aux) && leaf_hit(n, r, t1 + (real)0.001, (real)INFINITY, t2, aux)) {
+                t1 = max_r(t1, t_min);
+                t2 = min_r(t2, closest);
+                if (t1 < t2) {
+                    t1 = max_r(t1, (real)0);
+                    const real ray_scale = sqrt_r(length_squared(d));
+                    const real distance_inside = (t2 - t1) * ray_scale;
+                    const real hit_distance = ob.neg_inv_density * log_r(rng_range(g, key, (real)0, (real)1));
+                    if (!(hit_distance > distance_inside)) {
+                        const real t = t1 + div_r(hit_distance, ray_scale);
+                        closest = t; rec.t = t; rec.obj = k; rec.node = -1; rec.aux = 0; any = true;
+                    }
+                }
+            }
+        }
+    }
+    return any;
+}
+
+// ---------------------------------------------------------------------------------------------- textures
+DEV real perlin_noise(const Scene& S, int table, V3 p) {  // textures.rs:90-134
+    const real fx = floor_r(p.x), fy = floor_r(p.y), fz = floor_r(p.z);
+    const real u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const real uu = u * u * ((real)3 - (real)2 * u), vv = v * v * ((real)3 - (real)2 * v), ww = w * w * ((real)3 - (real)2 * w);
+    const real* vec = S.perlin_vec + (size_t)table * 3072;
+    const uint16_t* perm = S.perlin_perm + (size_t)table * 3072;
+    real accum = (real)0;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                const int idx = perm[(i + di) & 1023] ^ perm[1024 + ((j + dj) & 1023)] ^ perm[2048 + ((k + dk) & 1023)];
+                const V3 c = mk(vec[idx * 3], vec[idx * 3 + 1], vec[idx * 3 + 2]);
+                const V3 weight = mk(u - (real)di, v - (real)dj, w - (real)dk);
+                accum += ((real)di * uu + (real)(1 - di) * ((real)1 - uu)) * ((real)dj * vv + (real)(1 - dj) * ((real)1 - vv)) *
+                         ((real)dk * ww + (real)(1 - dk) * ((real)1 - ww)) * dot(weight, c);
+            }
+    return accum;
+}
+DEV real perlin_turbulence(const Scene& S, int table, V3 p) {  // textures.rs:76-88, depth 7
+    real accum = (real)0, weight = (real)1;
+    V3 tp = p;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * perlin_noise(S, table, tp);
+        weight *= (real)0.5;
+        tp = (real)2 * tp;
+    }
+    return abs_r(accum);
+}
+DEV V3 texture_value(const Scene& S, int tex, real u, real v, V3 p) {
+    DTexture<real> t = S.textures[tex];
+    for (int guard = 0; guard < 8 && t.kind == MLRT_TEX_CHECKER; guard++) {  // textures.rs:40-49
+        const real sines = sin_r((real)5 * p.x) * sin_r((real)5 * p.y) * sin_r((real)5 * p.z);
+        t = S.textures[sines < (real)0 ? t.a : t.b];
+    }
+    if (t.kind == MLRT_TEX_SOLID) return ld3(t.color);
+    if (t.kind == MLRT_TEX_NOISE) {  // textures.rs:163-167
+        const real x = (real)1 + sin_r(t.scale * p.z + (real)10 * perlin_turbulence(S, t.a, t.scale * p));
+        return mk((real)0.5 * x, (real)0.5 * x, (real)0.5 * x);
+    }
+    if (t.kind == MLRT_TEX_IMAGE) {  // image_texture.rs:16-28
+        const DImage im = S.images[t.a];
+        const real uc = min_r(max_r(u, (real)0), (real)1);
+        const real vc = min_r(max_r((real)1 - v, (real)0), (real)1);
+        unsigned int i = (unsigned int)(uc * (real)im.width);
+        unsigned int j = (unsigned int)(vc * (real)im.height);
+        i = min(i, (unsigned int)im.width - 1u);
+        j = min(j, (unsigned int)im.height - 1u);
+        const uint8_t* px = im.rgb + ((size_t)j * (size_t)im.width + i) * 3;
+        return mk((real)px[0] / (real)255, (real)px[1] / (real)255, (real)px[2] / (real)255);
+    }
+    return mk(0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------- shading
+DEV V3 reflect(V3 v, V3 n) { return v - ((real)2 * dot(v, n)) * n; }  // materials.rs:47-49
+DEV V3 refract(V3 uv, V3 n, real etai_over_etat) {                    // materials.rs:63-68
+    const real cos_theta = min_r(dot(-uv, n), (real)1);
+    const V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    const V3 r_out_parallel = (-sqrt_r(abs_r((real)1 - length_squared(r_out_perp)))) * n;
+    return r_out_perp + r_out_parallel;
+}
+DEV real reflectance(real cos_theta, real refraction_ratio) {  // materials.rs:81-86
+    const real r0 = div_r((real)1 - refraction_ratio, (real)1 + refraction_ratio);
+    const real r0_sq = r0 * r0;
+    const real x = (real)1 - cos_theta;
+    const real x2 = x * x;
+    return r0_sq + ((real)1 - r0_sq) * (x * (x2 * x2));  // powi(5)
+}
+DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
+    const double pi = 3.14159265358979323846264338327950288;
+    if (kFast) {
+        const float theta = acosf(-(float)n.y);
+        const float phi = atan2f(-(float)n.z, (float)n.x) + (float)pi;
+        u = (real)(phi * (float)(1.0 / (2.0 * pi)));
+        v = (real)(theta * (float)(1.0 / pi));
+    } else {
+        const double theta = acos(-(double)n.y);
+        const double phi = atan2(-(double)n.z, (double)n.x) + pi;
+        u = (real)(phi / (2.0 * pi));
+        v = (real)(theta / pi);
+    }
+}
+
+// Evaluate the hit found by world_hit and the material response.  Returns true when the path continues with
+// (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
+DEV bool shade(const Scene& S, const HitRec& rec, V3& o, V3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
+    const DObject<real> ob = S.objects[rec.obj];
+    V3 p, normal;
+    real u = (real)0, v = (real)0;
+    bool front_face = true;
+    int mat_id;
+    if (rec.node < 0) {  // volumes.rs:55-63
+        p = o + rec.t * d;
+        normal = mk((real)1, (real)0, (real)0);
+        mat_id = ob.phase_mat;
+    } else {
+        const DNode<real> n = S.nodes[rec.node];
+        mat_id = n.link;
+        V3 oo = o, od = d;
+        if (ob.xform) to_object(ob, oo, od);
+        const V3 po = oo + rec.t * od;  // Ray::at
+        const int kind = n.tag & TAG_KIND_MASK;
+        V3 outward;
+        if (kind == TAG_SPHERE) {
+            const V3 c = mk(n.v[0], n.v[1], n.v[2]);
+            if (kFast) outward = (po - c) * fast_rcp(n.v[3]);
+            else outward = mk((po.x - c.x) / n.v[3], (po.y - c.y) / n.v[3], (po.z - c.z) / n.v[3]);
+            if (S.materials[mat_id].kind & MATFLAG_NEEDS_UV) sphere_uv(outward, u, v);
+        } else if (kind == TAG_BOX) {
+            outward = axis_vec(rec.aux, (real)1);
+        } else {
+            const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
+            outward = axis_vec(ap, (real)1);
+            u = div_r(comp(po, a0) - n.v[0], n.v[1] - n.v[0]);
+            v = div_r(comp(po, a1) - n.v[2], n.v[3] - n.v[2]);
+        }
+        front_face = dot(outward, od) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
+        normal = front_face ? outward : -outward;
+        p = po;
+        if (ob.xform & XF_ROTATE) {  // Rotate::hit, transforms.rs:134-139 (quirk Q10: world normal vs object-space ray)
+            p = rotate_fwd(ob, p);
+            const V3 nw = rotate_fwd(ob, normal);
+            front_face = dot(nw, od) < (real)0;
+            normal = front_face ? nw : -nw;
+        }
+        if (ob.xform & XF_TRANSLATE) {  // Translate::hit, transforms.rs:36-39 (moved_r.dir == r.dir)
+            p = p + ld3(ob.off);
+            front_face = dot(normal, d) < (real)0;
+            normal = front_face ? normal : -normal;
+        }
+    }
+    const DMaterial<real> m = S.materials[mat_id];
+    const int mk_kind = m.kind & 0xFF;
+    if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
+        V3 s = random_in_unit_sphere(g, key);
+        if (!(dot(normal, s) > (real)0)) s = -s;  // random_in_hemisphere, vec.rs:36-43
+        V3 dir = normal + s;
+        const real eps = (real)1e-8;
+        if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
+        thr = thr * texture_value(S, m.tex, u, v, p);
+        o = p; d = dir;
+        return true;
+    }
+    if (mk_kind == MLRT_MAT_METAL) {  // materials.rs:51-61 (quirk Q7)
+        const V3 reflected = reflect(unit(d), normal);
+        const V3 dir = reflected + m.param * random_in_unit_sphere(g, key);
+        if (dot(dir, normal) > (real)0) {
+            thr = thr * ld3(m.albedo);
+            o = p; d = dir;
+            return true;
+        }
+        emitted = mk(0, 0, 0);  // Material::emit default, materials.rs:9-11
+        return false;
+    }
+    if (mk_kind == MLRT_MAT_DIELECTRIC) {  // materials.rs:88-106 (quirk Q8)
+        const real refraction_ratio = !front_face ? m.param : div_r((real)1, m.param);
+        const V3 unit_direction = unit(d);
+        const real cos_theta = min_r(dot(normal, -unit_direction), (real)1);
+        const real sin_theta = sqrt_r((real)1 - cos_theta * cos_theta);
+        const bool cannot_refract = refraction_ratio * sin_theta > (real)1;
+        V3 dir;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_range(g, key, (real)0, (real)1)) dir = reflect(unit_direction, normal);
+        else dir = refract(unit_direction, normal, refraction_ratio);
+        o = p; d = dir;
+        return true;
+    }
+    if (mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
+        const V3 dir = random_in_unit_sphere(g, key);
+        thr = thr * texture_value(S, m.tex, u, v, p);
+        o = p; d = dir;
+        return true;
+    }
+    emitted = texture_value(S, m.tex, u, v, p);  // DiffuseLight, materials.rs:119-127
+    return false;
+}
+
+DEV V3 background_color(const KParams<real>& P, V3 d) {  // raytrace.rs:29-35, 44-48
+    if (P.bg_kind == MLRT_BG_BLACK) return mk(0, 0, 0);
+    const V3 ud = unit(d);
+    const real t = (real)0.5 * (ud.y + (real)1);
+    return ((real)1 - t) * ld3(P.bg_bottom) + t * ld3(P.bg_top);
+}
+
+DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j, V3& o, V3& d) {  // raytrace.rs:191-193, camera.rs:40-48
+    const real s = div_r((real)i + rng_range(g, key, (real)0, (real)1), (real)P.width - (real)1);
+    const real t = div_r((real)j + rng_range(g, key, (real)0, (real)1), (real)P.height - (real)1);
+    real a, b;
+    for (;;) {  // random_in_unit_disk, vec.rs:45-52 (quirk Q6: drawn even when lens_radius == 0)
+        a = rng_range(g, key, (real)-1, (real)1);
+        b = rng_range(g, key, (real)-1, (real)1);
+        if (a * a + b * b < (real)1) break;
+    }
+    const real rdx = P.lens_radius * a, rdy = P.lens_radius * b;
+    const V3 offset = ld3(P.cam_u) * rdx + ld3(P.cam_v) * rdy;
+    const V3 origin = ld3(P.cam_origin);
+    o = origin + offset;
+    d = ld3(P.cam_llc) + s * ld3(P.cam_horizontal) + t * ld3(P.cam_vertical) - origin - offset;
+}
+
+// 2^-32 fixed point; integer accumulation is order independent.  NaN/negative radiance cannot occur on this
+// path (near_zero guard, abs() under the refraction root); they are clamped to 0 rather than poisoning the sum.
+DEV unsigned long long to_fixed(real c) {
+    double x = (double)c;
+    if (!(x > 0.0)) x = 0.0;
+    if (x > 1048576.0) x = 1048576.0;
+    return (unsigned long long)(x * 4294967296.0 + 0.5);
+}
+
+template <bool LDS_SCENE>
+__global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<real> P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    const unsigned char* base;
+    unsigned char* acc_base;
+    if (LDS_SCENE) {
+        // stage the packed scene: 16 B per lane per step, fully coalesced
+        const uint4* src = reinterpret_cast<const uint4*>(P.blob);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const int n16 = P.blob_bytes >> 4;
+        for (int i = threadIdx.x; i < n16; i += MLRT_BLOCK) dst[i] = src[i];
+        __syncthreads();
+        base = smem;
+        acc_base = smem + P.blob_bytes;
+    } else {
+        base = P.blob;
+        acc_base = smem;
+    }
+    Scene S;
+    S.nodes = reinterpret_cast<const DNode<real>*>(base + P.off_nodes);
+    S.objects = reinterpret_cast<const DObject<real>*>(base + P.off_objects);
+    S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
+    S.textures = reinterpret_cast<const DTexture<real>*>(base + P.off_textures);
+    S.perlin_vec = reinterpret_cast<const real*>(base + P.off_perlin_vec);
+    S.perlin_perm = reinterpret_cast<const uint16_t*>(base + P.off_perlin_perm);
+    S.images = P.images;
+
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_base + wave * kAccBytesPerWave);
+    const RngKey key = {P.seed_lo, P.seed_hi};
+    const int spp = P.spp;
+
+    for (;;) {
+        // one tile per wave at a time, pulled from the global queue
+        int tile = 0;
+        if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= P.n_tiles) break;
+        const int row_k = tile / P.tiles_per_row;
+        const int x0 = (tile - row_k * P.tiles_per_row) * P.pix_per_tile;
+        const int npix = min(P.pix_per_tile, P.width - x0);
+        const int j = P.rows ? P.rows[row_k] : row_k;
+        for (int i = lane; i < npix * 3; i += 64) acc[i] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const int total = npix * spp;  // the tile's sample queue
+        int next = 0;                  // wave-uniform queue head
+        bool alive = false;
+        int pix = 0, depth = 0;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
+        Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+        for (;;) {
+            // path regeneration: lanes without a live path take the next queue entries in lane order
+            const unsigned long long need = __ballot(!alive);
+            if (need != 0ull && next < total) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
+                const int q = next + rank;
+                if (!alive && q < total) {
+                    pix = q / spp;
+                    const int s = q - pix * spp;
+                    g.pixel = (uint32_t)(j * P.width + x0 + pix);
+                    g.sample = (uint32_t)s;
+                    g.draw = 0u;
+                    gen_camera_ray(P, g, key, x0 + pix, j, o, d);
+                    thr = mk(1, 1, 1);
+                    depth = P.max_depth;
+                    alive = true;
+                }
+                next += __popcll(need);
+            }
+            if (__ballot(alive) == 0ull) break;
+            if (alive) {
+                V3 radiance = mk(0, 0, 0);
+                bool done;
+                if (depth <= 0) {  // raytrace.rs:87-89
+                    done = true;
+                } else {
+                    HitRec rec;
+                    rec.t = 0; rec.obj = 0; rec.node = 0; rec.aux = 0;
+                    if (world_hit(S, P.n_objects, o, d, g, key, rec)) {
+                        V3 emitted = mk(0, 0, 0);
+                        if (shade(S, rec, o, d, thr, emitted, g, key)) { done = false; depth--; }
+                        else { done = true; radiance = thr * emitted; }
+                    } else {
+                        done = true;
+                        radiance = thr * background_color(P, d);
+                    }
+                }
+                if (done) {
+                    atomicAdd(&acc[pix * 3 + 0], to_fixed(radiance.x));
+                    atomicAdd(&acc[pix * 3 + 1], to_fixed(radiance.y));
+                    atomicAdd(&acc[pix * 3 + 2], to_fixed(radiance.z));
+                    alive = false;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // fused epilogue: to_rgb (raytrace.rs:59-68) in f64 for every pixel of the tile
+        for (int i = lane; i < npix * 3; i += 64) {
+            const double sum = (double)acc[i] * (1.0 / 4294967296.0);
+            const size_t out = ((size_t)row_k * P.width + x0) * 3 + i;
+            if (P.accum_out) P.accum_out[out] = sum;
+            const double scale = 1.0 / (double)spp;
+            double c = sqrt(sum * scale);
+            c = c < 0.0 ? 0.0 : (c > 0.99999999 ? 0.99999999 : c);
+            P.rgb_out[out] = (int32_t)(255.999 * c);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace MLRT_NS
+
+// ---------------------------------------------------------------------------------------------- launcher
+
+extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream) {
+    const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
+    hipError_t e;
+    if (lds_scene) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&MLRT_NS::mlrt_render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<true>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
+    } else {
+        hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<false>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
+    }
+    return (int)hipGetLastError();
+}
+extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(void) { return MLRT_BLOCK; }
+extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(void) { return MLRT_NS::kAccBytesPerWave; }
+extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int lds_scene, size_t dyn_lds) {
+    int blocks = 0;
+    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, MLRT_NS::mlrt_render_kernel<true>, MLRT_BLOCK, dyn_lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, MLRT_NS::mlrt_render_kernel<false>, MLRT_BLOCK, dyn_lds);
+    return e == hipSuccess ? blocks : -1;
+}

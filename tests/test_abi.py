@@ -1,0 +1,61 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol the headers declare, and its compute
+entry points fail loudly (no CPU fallback) when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlrt_[a-z0-9_]+)\s*\(", text)) - {"mlrt_progress_fn"})
+
+
+def test_every_declared_symbol_is_exported(mlrt):
+    L = mlrt.lib()
+    for header, listed in (("mlrt.h", mlrt.EXPORTS_MLRT_H), ("mlrt_host.h", mlrt.EXPORTS_MLRT_HOST_H)):
+        declared = _declared(header)
+        assert declared == sorted(listed), header
+        for name in declared:
+            assert hasattr(L, name), name
+
+
+def test_version(mlrt):
+    major, minor = C.c_int32(-1), C.c_int32(-1)
+    mlrt.lib().mlrt_version(C.byref(major), C.byref(minor))
+    assert (major.value, minor.value) == (0, 1)
+
+
+def test_struct_sizes_match_the_header(mlrt):
+    # natural-alignment sizes of the POD structs in include/mlrt.h
+    assert C.sizeof(mlrt.Material) == 40 and C.sizeof(mlrt.Texture) == 48 and C.sizeof(mlrt.Sphere) == 40 and C.sizeof(mlrt.Box) == 56
+    assert C.sizeof(mlrt.Rect) == 56 and C.sizeof(mlrt.BvhNode) == 56 and C.sizeof(mlrt.Transform) == 56 and C.sizeof(mlrt.Object) == 32
+    assert C.sizeof(mlrt.CameraStruct) == 152 and C.sizeof(mlrt.Params) == 80
+
+
+def test_invalid_scene_is_rejected_before_touching_a_device(mlrt):
+    w = mlrt.World("random", 42)
+    scene = mlrt.Scene()
+    C.memmove(C.byref(scene), w.scene, C.sizeof(mlrt.Scene))
+    scene.n_objects = 0
+    ctx = C.c_void_p()
+    rc = mlrt.lib().mlrt_context_create(C.byref(scene), 0, mlrt.PRECISION_FP32, C.byref(ctx))
+    assert rc == mlrt.MLRT_ERR_INVALID and not ctx.value
+    assert b"no objects" in mlrt.lib().mlrt_last_error()
+    w.close()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback_without_a_device(mlrt):
+    assert mlrt.device_count() == 0
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    p = mlrt.make_params(w, 40, 26, 2)
+    with pytest.raises(mlrt.MlrtError) as e:
+        mlrt.Renderer(w, cam, p)
+    assert e.value.code == mlrt.MLRT_ERR_NO_DEVICE
+    w.close()
