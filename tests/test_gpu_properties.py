@@ -1,0 +1,121 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (where the oracle would take minutes):
+determinism, row-tiling invariance (the multi-GPU decomposition), the C-ABI host and device entry points agreeing, and
+the full-size image against the reference's README render."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_rows.npz"))
+
+
+@pytest.fixture(scope="module")
+def c2(mlrt):
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    params = mlrt.make_params(w, 1200, 800, 500)
+    r = mlrt.Renderer(w, cam, params)
+    img = r.render()
+    yield mlrt, w, cam, params, r, img
+    r.close()
+    w.close()
+
+
+def test_full_size_image_matches_readme_render(c2):
+    """BASELINE.json configs[1] in full (480 M samples) vs the decoded rows of sample.jpg: the JPEG-error floor of SURVEY 8c."""
+    _, _, _, _, _, img = c2
+    rows = GOLD["sample_rows"]
+    mine = np.stack([img[j] for j in rows]).astype(np.float64)
+    ref = GOLD["sample_rgb"].astype(np.float64)
+    rmse = np.sqrt(np.mean((mine - ref) ** 2)) / 255.0
+    assert rmse < 0.0095, rmse
+    blur = np.sqrt(np.mean((mine - GOLD["sample_blur_rgb"].astype(np.float64)) ** 2)) / 255.0
+    assert blur > 2 * rmse
+
+
+def test_render_is_deterministic(c2):
+    mlrt, w, cam, params, r, img = c2
+    again = r.render()
+    assert np.array_equal(img, again)
+
+
+def test_row_tiling_invariance(c2):
+    """Rendering any subset of rows gives exactly the rows of the full image: the property that makes the 1/2/4/8-GPU
+    images bit-identical (rows are dealt to ranks in interleaved blocks, bench.py rows_for_rank)."""
+    mlrt, w, cam, params, r, img = c2
+    for world_size in (2, 8):
+        for rank in (0, world_size - 1):
+            rows = np.array([j for j in range(800) if (j // 8) % world_size == rank][::5], dtype=np.int32)
+            part = r.render(rows)
+            assert np.array_equal(part, img[rows])
+
+
+def test_device_entry_point_equals_host_entry_point(c2):
+    torch = pytest.importorskip("torch")
+    mlrt, w, cam, params, r, img = c2
+    rows = np.arange(0, 800, 37, dtype=np.int32)
+    d_rows = torch.tensor(rows, device="cuda")
+    d_rgb = torch.zeros((len(rows), 1200, 3), dtype=torch.int32, device="cuda")
+    d_acc = torch.zeros((len(rows), 1200, 3), dtype=torch.float64, device="cuda")
+    r.render_device(d_rows.data_ptr(), len(rows), d_rgb.data_ptr(), d_acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_rgb.cpu().numpy(), img[rows])
+    # the accumulation buffer is the pre-gamma colour sum: to_rgb of it reproduces the image
+    acc = d_acc.cpu().numpy()
+    c = np.clip(np.sqrt(acc / 500.0), 0.0, 0.99999999)
+    assert np.array_equal((255.999 * c).astype(np.int32), img[rows])
+    assert r.last_kernel_ms() > 0
+
+
+def test_one_shot_entry_point_and_progress(mlrt):
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    params = mlrt.make_params(w, 200, 133, 4)
+    out = np.zeros((133, 200, 3), dtype=np.int32)
+    seen = []
+    cb = mlrt.PROGRESS_FN(lambda done, total, user: seen.append((done, total)))
+    rc = mlrt.lib().mlrt_render(w.scene, C.byref(cam), C.byref(params), mlrt.PRECISION_FP32, out.ctypes.data_as(C.c_void_p), C.cast(cb, C.c_void_p), None)
+    assert rc == 0 and seen and seen[-1] == (133, 133) and all(a[0] < b[0] for a, b in zip(seen, seen[1:]))
+    r = mlrt.Renderer(w, cam, params)
+    assert np.array_equal(r.render(), out)
+    r.close()
+    w.close()
+
+
+def test_bad_arguments_fail_loudly(mlrt):
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    params = mlrt.make_params(w, 200, 133, 4)
+    r = mlrt.Renderer(w, cam, params)
+    with pytest.raises(mlrt.MlrtError):
+        r.render(np.array([5, 133], dtype=np.int32))  # row out of range
+    params.samples_per_pixel = 0
+    with pytest.raises(mlrt.MlrtError):
+        r.render()
+    params.samples_per_pixel = 4
+    with pytest.raises(mlrt.MlrtError):
+        mlrt.Renderer(w, cam, params, device=99)
+    r.close()
+    w.close()
+
+
+def test_cli_is_a_drop_in_for_the_reference_command_line(mlrt, oracle, tmp_path):
+    """`mlrt --world=random --seed=42 --aspect_ratio=3:2 --image_width=400 --samples_per_pixel=8` prints the P3 image the
+    library renders (main.rs:144,175-179), top row first."""
+    out = subprocess.run([mlrt.CLI_PATH, "--world=random", "--seed=42", "--aspect_ratio=3:2", "--image_width=400", "--samples_per_pixel=8"],
+                         capture_output=True, text=True, check=True)
+    lines = out.stdout.split("\n")
+    assert lines[:3] == ["P3", "400 266", "255"]
+    px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 400 * 266]], dtype=np.int32).reshape(266, 400, 3)[::-1]
+    assert "Rendered in" in out.stderr
+    w = mlrt.World("random", 42)
+    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8))
+    assert np.array_equal(px, r.render())
+    r.close()
+    w.close()
+    bad = subprocess.run([mlrt.CLI_PATH, "--world=nope", "--seed=1"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "possible values" in bad.stderr
