@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmlrt_hip.so")
+LIB_PATH = os.environ.get("MLRT_LIB") or os.path.join(_HERE, "lib", "libmlrt_hip.so")  # MLRT_LIB: A/B builds
 CLI_PATH = os.path.join(_HERE, "bin", "mlrt")
 EARTHMAP_PPM = os.path.join(os.path.dirname(_HERE), "assets", "earthmap.ppm")
 

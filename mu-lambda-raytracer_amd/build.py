@@ -13,19 +13,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_DIR = os.path.join(HERE, "lib")
 BIN_DIR = os.path.join(HERE, "bin")
-OBJ_DIR = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(LIB_DIR, "libmlrt_hip.so")
+OBJ_DIR = os.path.join(HERE, "lib", "obj" + os.environ.get("MLRT_TAG", ""))
+LIB = os.path.join(LIB_DIR, "libmlrt_hip%s.so" % os.environ.get("MLRT_TAG", ""))
 CLI = os.path.join(BIN_DIR, "mlrt")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-BLOCK = os.environ.get("MLRT_BLOCK", "512")
+BLOCK = os.environ.get("MLRT_BLOCK", "768")
+# experiment hooks: MLRT_TAG builds a side-by-side variant (lib/libmlrt_hip<tag>.so, loaded with MLRT_LIB=<path>);
+# MLRT_KERNEL_FLAGS appends flags to the f32 kernel compile (e.g. "-DMLRT_X=1")
+TAG = os.environ.get("MLRT_TAG", "")
+EXTRA_KERNEL_FLAGS = os.environ.get("MLRT_KERNEL_FLAGS", "").split()
 
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(ROOT, "include")]
 KERNEL = os.path.join(HERE, "csrc", "mlrt_kernel.hip")
 UNITS = [
     # (object, source, extra flags)
-    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-ffp-contract=fast"]),
+    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-ffp-contract=fast"] + EXTRA_KERNEL_FLAGS),
     # parity build: no FMA contraction, so every rounding sits where the reference (and the oracle) has it
     ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=256", "-ffp-contract=off"]),
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
@@ -63,6 +67,8 @@ def build(force=False, verbose_resources=False):
     if force or _stale(LIB, objs):
         _run([HIPCC, "-shared", "-fPIC", "-o", LIB] + objs)
     main_src = os.path.join(HERE, "host", "main.cpp")
+    if TAG:
+        return LIB
     if force or _stale(CLI, [main_src, LIB] + HEADERS):
         _run([HIPCC] + COMMON + ["-ffp-contract=off", main_src, "-o", CLI, "-L", LIB_DIR, "-lmlrt_hip", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB

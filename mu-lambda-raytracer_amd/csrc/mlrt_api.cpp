@@ -266,12 +266,12 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.n_objects = c->n_objects;
     K.images = c->d_images;
     for (int k = 0; k < 3; k++) {
-        K.cam_origin[k] = (R)cam->origin[k]; K.cam_llc[k] = (R)cam->lower_left_corner[k];
-        K.cam_horizontal[k] = (R)cam->horizontal[k]; K.cam_vertical[k] = (R)cam->vertical[k];
-        K.cam_u[k] = (R)cam->u[k]; K.cam_v[k] = (R)cam->v[k];
+        K.cam_origin[k] = cam->origin[k]; K.cam_llc[k] = cam->lower_left_corner[k];
+        K.cam_horizontal[k] = cam->horizontal[k]; K.cam_vertical[k] = cam->vertical[k];
+        K.cam_u[k] = cam->u[k]; K.cam_v[k] = cam->v[k];
         K.bg_top[k] = (R)p->background_top[k]; K.bg_bottom[k] = (R)p->background_bottom[k];
     }
-    K.lens_radius = (R)cam->lens_radius;
+    K.lens_radius = cam->lens_radius;
     K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;

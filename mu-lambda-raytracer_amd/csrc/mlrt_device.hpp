@@ -76,9 +76,9 @@ struct KParams {
     int32_t off_nodes, off_objects, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
     int32_t n_objects;
     const DImage* images;
-    // Camera (camera.rs:3-12)
-    R cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
-    R lens_radius;
+    // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does
+    double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
+    double lens_radius;
     int32_t width, height, spp, max_depth;
     uint32_t seed_lo, seed_hi;
     int32_t bg_kind;

@@ -2,7 +2,7 @@
 // intersection arithmetic, not a contraction), no CUDA shims, no second back end.
 //
 // Compiled twice (see mu-lambda-raytracer_amd/build.py):
-//   -DMLRT_REAL=float                        -> fast path:   f32 rays / boxes, f64 island for the sphere quadratic
+//   -DMLRT_REAL=float                        -> fast path:   f64 ray state + sphere quadratic, f32 boxes/rects/shading
 //   -DMLRT_REAL=double -ffp-contract=off     -> parity path: f64 throughout, the reference's operation order
 //
 // What it replaces (reference file:line):
@@ -91,6 +91,20 @@ DEV real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV real length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 DEV real comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 DEV V3 axis_vec(int i, real s) { return mk(i == 0 ? s : (real)0, i == 1 ? s : (real)0, i == 2 ? s : (real)0); }
+// Geometry state (ray origin, direction, hit point) is f64 in BOTH builds: an f32 ulp of a ~500-unit coordinate
+// (6e-5) is enough to flip accept/reject decisions against the oracle in dense geometry (final_scene foam).
+struct P3 {
+    double x, y, z;
+};
+DEV P3 mkp(double x, double y, double z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV P3 to_p3(V3 a) { return mkp((double)a.x, (double)a.y, (double)a.z); }
+DEV V3 to_v3(P3 a) { return mk((real)a.x, (real)a.y, (real)a.z); }
+DEV P3 ld3p(const double* p) { return mkp(p[0], p[1], p[2]); }
+DEV P3 operator+(P3 a, P3 b) { return mkp(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV P3 operator-(P3 a, P3 b) { return mkp(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV P3 operator*(P3 a, double s) { return mkp(a.x * s, a.y * s, a.z * s); }
+DEV P3 operator*(double s, P3 a) { return mkp(a.x * s, a.y * s, a.z * s); }
+DEV double compp(P3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 // Vec3::unit = self / self.length() (vec.rs:67-69): per-component division in the parity build
 DEV V3 unit(V3 a) {
     if (kFast) {
@@ -102,11 +116,15 @@ DEV V3 unit(V3 a) {
 }
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
-// One stream per (pixel, sample): counter = (draw/4, sample, pixel, 0), key = seed; draw k is word k%4.
-// Identical to PhiloxStream in oracle/oracle_core.hpp, word for word.
+// One stream per (pixel, sample): counter = (draw/4, sample, pixel, 0), key = seed; draw k is word k%4 of block k/4.
+// Identical to PhiloxStream in oracle/oracle_core.hpp, word for word.  next3/next4 read several consecutive words
+// with ONE refill site: the draw order is unchanged, only the number of divergent refill branches drops.
 struct Rng {
     uint32_t pixel, sample, draw;
     uint32_t b0, b1, b2, b3;
+};
+struct RngKey {
+    uint32_t k0, k1;
 };
 DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0, uint32_t& o1,
                        uint32_t& o2, uint32_t& o3) {
@@ -119,24 +137,31 @@ DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-struct RngKey {
-    uint32_t k0, k1;
-};
+DEV void rng_fill(Rng& g, RngKey key, uint32_t block) { philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3); }
 DEV uint32_t rng_next(Rng& g, RngKey key) {
     const uint32_t i = g.draw & 3u;
-    if (i == 0) philox4x32_10(key.k0, key.k1, g.draw >> 2, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3);
+    if (i == 0) rng_fill(g, key, g.draw >> 2);
     g.draw++;
     return i == 0 ? g.b0 : (i == 1 ? g.b1 : (i == 2 ? g.b2 : g.b3));
 }
-DEV real rng_uniform(Rng& g, RngKey key) { return (real)(rng_next(g, key) >> 8) * (real)(1.0 / 16777216.0); }
+DEV void rng_next3(Rng& g, RngKey key, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t k = g.draw & 3u;
+    const uint32_t o1 = g.b1, o2 = g.b2, o3 = g.b3;
+    if (k != 1u) rng_fill(g, key, (g.draw + 3u) >> 2);  // k == 0: the current block; k == 2, 3: the next one
+    g.draw += 3u;
+    w0 = k == 0 ? g.b0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+    w1 = k == 0 ? g.b1 : (k == 1 ? o2 : (k == 2 ? o3 : g.b0));
+    w2 = k == 0 ? g.b2 : (k == 1 ? o3 : (k == 2 ? g.b0 : g.b1));
+}
+DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
+DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
 // rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
-DEV real rng_range(Rng& g, RngKey key, real lo, real hi) { return rng_uniform(g, key) * (hi - lo) + lo; }
-DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {  // vec.rs:23-30
+DEV real sym(uint32_t w) { return u01(w) * (real)2 + (real)-1; }  // gen_range(-1.0..1.0)
+DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {                // vec.rs:23-30
     for (;;) {
-        const real a = rng_range(g, key, (real)-1, (real)1);
-        const real b = rng_range(g, key, (real)-1, (real)1);
-        const real c = rng_range(g, key, (real)-1, (real)1);
-        const V3 p = mk(a, b, c);
+        uint32_t w0, w1, w2;
+        rng_next3(g, key, w0, w1, w2);
+        const V3 p = mk(sym(w0), sym(w1), sym(w2));
         if (length_squared(p) < (real)1) return p;
     }
 }
@@ -152,54 +177,53 @@ struct Scene {
     const DImage* images;           // HBM (L2-resident)
 };
 
+// A ray as the intersection routines see it: the f64 geometry state plus (fast build) its f32 image for the slabs.
 struct Ray {
-    V3 o, d;
-    V3 invd;       // fast build only
-    double a;      // |d|^2 for the sphere quadratic
-    double inv_a;  // fast build only
+    P3 o, d;       // f64, object space of the object being tested
+    V3 of, invd;   // fast build: (float)o and 1/(float)d
+    double a;      // |d|^2
+    double inv_a;  // fast build: 1/|d|^2
 };
-DEV Ray make_ray(V3 o, V3 d) {
-    Ray r;
-    r.o = o; r.d = d;
-    r.a = (double)d.x * (double)d.x + (double)d.y * (double)d.y + (double)d.z * (double)d.z;
+DEV void finish_ray(Ray& r) {
+    r.a = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
     if (kFast) {
-        r.invd = mk(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-        // reciprocal of |d|^2 to f64 accuracy from an f32 seed + 2 Newton steps (no f64 divide in the hot loop)
+        r.of = to_v3(r.o);
+        r.invd = mk(fast_rcp((real)r.d.x), fast_rcp((real)r.d.y), fast_rcp((real)r.d.z));
+        // 1/|d|^2 to f64 accuracy: f32 seed + 2 Newton steps (no f64 divide in the hot loop)
         double x = (double)__builtin_amdgcn_rcpf((float)r.a);
         x = x * (2.0 - r.a * x);
         x = x * (2.0 - r.a * x);
         r.inv_a = x;
     } else {
-        r.invd = d;
+        r.of = to_v3(r.o);
+        r.invd = to_v3(r.d);
         r.inv_a = 0.0;
     }
-    return r;
 }
 
 // AABB::hit, bhv.rs:29-42 (quirk Q5).  Evaluating the three slabs and testing once equals the reference's
 // per-axis early exit because the interval only shrinks.
 DEV bool slab_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax) {
     real t0, t1;
-    if (kFast) { t0 = (n.v[0] - r.o.x) * r.invd.x; t1 = (n.v[3] - r.o.x) * r.invd.x; }
-    else { t0 = (n.v[0] - r.o.x) / r.d.x; t1 = (n.v[3] - r.o.x) / r.d.x; }
+    if (kFast) { t0 = (n.v[0] - r.of.x) * r.invd.x; t1 = (n.v[3] - r.of.x) * r.invd.x; }
+    else { t0 = (n.v[0] - (real)r.o.x) / (real)r.d.x; t1 = (n.v[3] - (real)r.o.x) / (real)r.d.x; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    if (kFast) { t0 = (n.v[1] - r.o.y) * r.invd.y; t1 = (n.v[4] - r.o.y) * r.invd.y; }
-    else { t0 = (n.v[1] - r.o.y) / r.d.y; t1 = (n.v[4] - r.o.y) / r.d.y; }
+    if (kFast) { t0 = (n.v[1] - r.of.y) * r.invd.y; t1 = (n.v[4] - r.of.y) * r.invd.y; }
+    else { t0 = (n.v[1] - (real)r.o.y) / (real)r.d.y; t1 = (n.v[4] - (real)r.o.y) / (real)r.d.y; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    if (kFast) { t0 = (n.v[2] - r.o.z) * r.invd.z; t1 = (n.v[5] - r.o.z) * r.invd.z; }
-    else { t0 = (n.v[2] - r.o.z) / r.d.z; t1 = (n.v[5] - r.o.z) / r.d.z; }
+    if (kFast) { t0 = (n.v[2] - r.of.z) * r.invd.z; t1 = (n.v[5] - r.of.z) * r.invd.z; }
+    else { t0 = (n.v[2] - (real)r.o.z) / (real)r.d.z; t1 = (n.v[5] - (real)r.o.z) / (real)r.d.z; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
     return !(tmax <= tmin);
 }
 
 // Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in BOTH builds: with the radius-1000 ground
 // sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
-// the f32 rate, so the island is cheap; the fast build avoids the f64 divide and square root instructions.
-DEV bool sphere_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out) {
-    const double ocx = (double)r.o.x - (double)n.v[0], ocy = (double)r.o.y - (double)n.v[1], ocz = (double)r.o.z - (double)n.v[2];
-    const double dx = (double)r.d.x, dy = (double)r.d.y, dz = (double)r.d.z;
+// the f32 rate, so this is affordable; the fast build avoids the f64 divide and square-root sequences.
+DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+    const double ocx = r.o.x - (double)n.v[0], ocy = r.o.y - (double)n.v[1], ocz = r.o.z - (double)n.v[2];
     const double radius = (double)n.v[3];
-    const double half_b = ocx * dx + ocy * dy + ocz * dz;
+    const double half_b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
     const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
     const double discriminant = half_b * half_b - r.a * c;
     if (discriminant < 0.0) return false;
@@ -216,33 +240,32 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, re
             sqrtd = s;
         }
         root = (-half_b - sqrtd) * r.inv_a;
-        if (root < (double)tmin || (double)tmax < root) {
+        if (root < tmin || tmax < root) {
             root = (-half_b + sqrtd) * r.inv_a;
-            if (root < (double)tmin || (double)tmax < root) return false;
+            if (root < tmin || tmax < root) return false;
         }
     } else {
         sqrtd = sqrt(discriminant);
         root = (-half_b - sqrtd) / r.a;
-        if (root < (double)tmin || (double)tmax < root) {
+        if (root < tmin || tmax < root) {
             root = (-half_b + sqrtd) / r.a;
-            if (root < (double)tmin || (double)tmax < root) return false;
+            if (root < tmin || tmax < root) return false;
         }
     }
-    t_out = (real)root;
+    t_out = root;
     return true;
 }
 
 // Block::hit = HittableList of six AARects (shapes.rs:172-192, hittable.rs:53-69): the nearest face hit inside
 // [tmin, tmax].  The faces a line can hit inside their rectangles are the slab entry and exit faces, so the six
 // rect tests collapse into one slab evaluation with the same t = (k - o)/d per face.
-DEV bool box_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out, int& axis_out) {
+DEV bool box_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& axis_out) {
     real lo[3], hi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const real oa = comp(r.o, a);
         real t0, t1;
-        if (kFast) { const real ia = comp(r.invd, a); t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
-        else { const real da = comp(r.d, a); t0 = (n.v[a] - oa) / da; t1 = (n.v[3 + a] - oa) / da; }
+        if (kFast) { const real oa = comp(r.of, a), ia = comp(r.invd, a); t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
+        else { const real oa = (real)compp(r.o, a), da = (real)compp(r.d, a); t0 = (n.v[a] - oa) / da; t1 = (n.v[3 + a] - oa) / da; }
         lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
     }
     real te = lo[0]; int ae = 0;
@@ -252,24 +275,33 @@ DEV bool box_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real&
     if (hi[1] < tx) { tx = hi[1]; ax = 1; }
     if (hi[2] < tx) { tx = hi[2]; ax = 2; }
     if (te > tx) return false;
-    if (te >= tmin && te <= tmax) { t_out = te; axis_out = ae; return true; }
-    if (tx >= tmin && tx <= tmax) { t_out = tx; axis_out = ax; return true; }
+    if ((double)te >= tmin && (double)te <= tmax) { t_out = (double)te; axis_out = ae; return true; }
+    if ((double)tx >= tmin && (double)tx <= tmax) { t_out = (double)tx; axis_out = ax; return true; }
     return false;
 }
 
 // AARect::hit, aarects.rs:45-64
-DEV bool rect_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out) {
+DEV bool rect_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
     const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
-    const real t = kFast ? (n.v[4] - comp(r.o, ap)) * comp(r.invd, ap) : (n.v[4] - comp(r.o, ap)) / comp(r.d, ap);
+    if (kFast) {
+        const real t = (n.v[4] - comp(r.of, ap)) * comp(r.invd, ap);
+        if ((double)t < tmin || (double)t > tmax) return false;
+        const real a0_v = comp(r.of, a0) + t * (real)compp(r.d, a0);
+        const real a1_v = comp(r.of, a1) + t * (real)compp(r.d, a1);
+        if (a0_v < n.v[0] || a0_v > n.v[1] || a1_v < n.v[2] || a1_v > n.v[3]) return false;
+        t_out = (double)t;
+        return true;
+    }
+    const double t = ((double)n.v[4] - compp(r.o, ap)) / compp(r.d, ap);
     if (t < tmin || t > tmax) return false;
-    const real a0_v = comp(r.o, a0) + t * comp(r.d, a0);
-    const real a1_v = comp(r.o, a1) + t * comp(r.d, a1);
-    if (a0_v < n.v[0] || a0_v > n.v[1] || a1_v < n.v[2] || a1_v > n.v[3]) return false;
+    const double a0_v = compp(r.o, a0) + t * compp(r.d, a0);
+    const double a1_v = compp(r.o, a1) + t * compp(r.d, a1);
+    if (a0_v < (double)n.v[0] || a0_v > (double)n.v[1] || a1_v < (double)n.v[2] || a1_v > (double)n.v[3]) return false;
     t_out = t;
     return true;
 }
 
-DEV bool leaf_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real& t_out, int& aux) {
+DEV bool leaf_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
     const int kind = n.tag & TAG_KIND_MASK;
     if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
     if (kind == TAG_BOX) return box_hit(n, r, tmin, tmax, t_out, aux);
@@ -277,79 +309,90 @@ DEV bool leaf_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax, real
     return false;  // TAG_EMPTY: shapes.rs:8-23
 }
 
-// Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132)
-DEV V3 rotate_back(const DObject<real>& ob, V3 v) {
+// Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132), in f64
+DEV P3 rotate_back(const DObject<real>& ob, P3 v) {
     const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const real v0 = comp(v, a0), v2 = comp(v, a2);
-    const real n0 = ob.cos_t * v0 - ob.sin_t * v2;
-    const real n2 = ob.sin_t * v0 + ob.cos_t * v2;
-    return mk(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+    const double v0 = compp(v, a0), v2 = compp(v, a2);
+    const double n0 = (double)ob.cos_t * v0 - (double)ob.sin_t * v2;
+    const double n2 = (double)ob.sin_t * v0 + (double)ob.cos_t * v2;
+    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
 }
-DEV V3 rotate_fwd(const DObject<real>& ob, V3 v) {  // transforms.rs:116-124
+DEV P3 rotate_fwd(const DObject<real>& ob, P3 v) {  // transforms.rs:116-124
     const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const real v0 = comp(v, a0), v2 = comp(v, a2);
-    const real n0 = ob.cos_t * v0 + ob.sin_t * v2;
-    const real n2 = -ob.sin_t * v0 + ob.cos_t * v2;
-    return mk(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+    const double v0 = compp(v, a0), v2 = compp(v, a2);
+    const double n0 = (double)ob.cos_t * v0 + (double)ob.sin_t * v2;
+    const double n2 = -(double)ob.sin_t * v0 + (double)ob.cos_t * v2;
+    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
 }
-DEV void to_object(const DObject<real>& ob, V3& o, V3& d) {
-    if (ob.xform & XF_TRANSLATE) o = o - ld3(ob.off);
+DEV void to_object(const DObject<real>& ob, P3& o, P3& d) {
+    if (ob.xform & XF_TRANSLATE) o = o - mkp((double)ob.off[0], (double)ob.off[1], (double)ob.off[2]);
     if (ob.xform & XF_ROTATE) { o = rotate_back(ob, o); d = rotate_back(ob, d); }
+}
+DEV Ray make_ray(const DObject<real>& ob, P3 o, P3 d) {
+    Ray r;
+    r.o = o; r.d = d;
+    if (ob.xform) to_object(ob, r.o, r.d);
+    finish_ray(r);
+    return r;
 }
 
 struct HitRec {
-    real t;
+    double t;
     int obj;   // index into objects
     int node;  // leaf node index (PRIM / BVH) or -1 for a medium
     int aux;   // box: face axis
 };
 
 // HittableList::hit over the top-level objects (hittable.rs:53-69) with closest_so_far shrinking in list order.
-DEV bool world_hit(const Scene& S, int n_objects, V3 o, V3 d, Rng& g, RngKey key, HitRec& rec) {
-    const real t_min = (real)0.001;  // raytrace.rs:90
-    real closest = (real)INFINITY;
+DEV bool world_hit(const Scene& S, int n_objects, P3 o, P3 d, Rng& g, RngKey key, HitRec& rec) {
+    const double t_min = 0.001;  // raytrace.rs:90
+    double closest = (double)INFINITY;
     bool any = false;
-    const Ray world_ray = make_ray(o, d);
+    Ray world_ray;
+    world_ray.o = o; world_ray.d = d;
+    finish_ray(world_ray);
     for (int k = 0; k < n_objects; k++) {
         const DObject<real> ob = S.objects[k];
         Ray r = world_ray;
-        if (ob.xform) {
-            V3 oo = o, od = d;
-            to_object(ob, oo, od);
-            r = make_ray(oo, od);
-        }
+        if (ob.xform) r = make_ray(ob, o, d);
         if (ob.kind == MLRT_OBJ_BVH) {
-            // Node::hit, bhv.rs:147-165, as a stackless walk of the threaded tree
+            // Node::hit, bhv.rs:147-165, as a stackless walk of the threaded tree.  "while-while": every lane first
+            // walks inner nodes until it stands on a leaf (or is done), then the leaves are tested together, so the
+            // expensive primitive code is not issued once per inner step for a handful of lanes.
             int node = ob.node_begin;
             const int end = ob.node_end;
-            while (node < end) {
-                const DNode<real> n = S.nodes[node];
-                if ((n.tag & TAG_KIND_MASK) == TAG_INNER) {
-                    node = slab_hit(n, r, t_min, closest) ? node + 1 : n.link;
-                } else {
-                    real t; int aux = 0;
-                    if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = node; rec.aux = aux; any = true; }
-                    node = node + 1;
+            for (;;) {
+                DNode<real> n;
+                n.tag = TAG_EMPTY;
+                while (node < end) {
+                    n = S.nodes[node];
+                    if ((n.tag & TAG_KIND_MASK) != TAG_INNER) break;
+                    node = slab_hit(n, r, (real)t_min, (real)closest) ? node + 1 : n.link;
                 }
+                if (node >= end) break;
+                double t; int aux = 0;
+                if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = node; rec.aux = aux; any = true; }
+                node = node + 1;
             }
         } else if (ob.kind == MLRT_OBJ_PRIM) {
             const DNode<real> n = S.nodes[ob.node_begin];
-            real t; int aux = 0;
+            double t; int aux = 0;
             if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = ob.node_begin; rec.aux = aux; any = true; }
         } else {
             // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
             const DNode<real> n = S.nodes[ob.node_begin];
-            real t1, t2; int aux = 0;
-            if (leaf_hit(n, r, (real)-INFINITY, (real)INFINITY, t1, aux) && leaf_hit(n, r, t1 + (real)0.001, (real)INFINITY, t2, aux)) {
-                t1 = max_r(t1, t_min);
-                t2 = min_r(t2, closest);
+            double t1, t2; int aux = 0;
+            if (leaf_hit(n, r, -(double)INFINITY, (double)INFINITY, t1, aux) && leaf_hit(n, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
+                t1 = fmax(t1, t_min);
+                t2 = fmin(t2, closest);
                 if (t1 < t2) {
-                    t1 = max_r(t1, (real)0);
-                    const real ray_scale = sqrt_r(length_squared(d));
-                    const real distance_inside = (t2 - t1) * ray_scale;
-                    const real hit_distance = ob.neg_inv_density * log_r(rng_range(g, key, (real)0, (real)1));
+                    t1 = fmax(t1, 0.0);
+                    const double ray_scale = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+                    const double distance_inside = (t2 - t1) * ray_scale;
+                    const double xi = u01d(rng_next(g, key));
+                    const double hit_distance = (double)ob.neg_inv_density * (kFast ? (double)logf((float)xi) : log(xi));
                     if (!(hit_distance > distance_inside)) {
-                        const real t = t1 + div_r(hit_distance, ray_scale);
+                        const double t = t1 + hit_distance / ray_scale;
                         closest = t; rec.t = t; rec.obj = k; rec.node = -1; rec.aux = 0; any = true;
                     }
                 }
@@ -449,52 +492,55 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
 
 // Evaluate the hit found by world_hit and the material response.  Returns true when the path continues with
 // (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
-DEV bool shade(const Scene& S, const HitRec& rec, V3& o, V3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
+DEV bool shade(const Scene& S, const HitRec& rec, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
     const DObject<real> ob = S.objects[rec.obj];
-    V3 p, normal;
+    P3 p;
+    V3 normal;
     real u = (real)0, v = (real)0;
     bool front_face = true;
     int mat_id;
-    if (rec.node < 0) {  // volumes.rs:55-63
+    const V3 dw = to_v3(d);  // world direction in shading precision
+    if (rec.node < 0) {      // volumes.rs:55-63
         p = o + rec.t * d;
         normal = mk((real)1, (real)0, (real)0);
         mat_id = ob.phase_mat;
     } else {
         const DNode<real> n = S.nodes[rec.node];
         mat_id = n.link;
-        V3 oo = o, od = d;
+        P3 oo = o, od = d;
         if (ob.xform) to_object(ob, oo, od);
-        const V3 po = oo + rec.t * od;  // Ray::at
+        const P3 po = oo + rec.t * od;  // Ray::at
+        const V3 odf = to_v3(od);
         const int kind = n.tag & TAG_KIND_MASK;
         V3 outward;
         if (kind == TAG_SPHERE) {
-            const V3 c = mk(n.v[0], n.v[1], n.v[2]);
-            if (kFast) outward = (po - c) * fast_rcp(n.v[3]);
-            else outward = mk((po.x - c.x) / n.v[3], (po.y - c.y) / n.v[3], (po.z - c.z) / n.v[3]);
+            if (kFast) outward = to_v3(po - mkp((double)n.v[0], (double)n.v[1], (double)n.v[2])) * fast_rcp(n.v[3]);
+            else outward = mk((real)((po.x - (double)n.v[0]) / (double)n.v[3]), (real)((po.y - (double)n.v[1]) / (double)n.v[3]), (real)((po.z - (double)n.v[2]) / (double)n.v[3]));
             if (S.materials[mat_id].kind & MATFLAG_NEEDS_UV) sphere_uv(outward, u, v);
         } else if (kind == TAG_BOX) {
             outward = axis_vec(rec.aux, (real)1);
         } else {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);
-            u = div_r(comp(po, a0) - n.v[0], n.v[1] - n.v[0]);
-            v = div_r(comp(po, a1) - n.v[2], n.v[3] - n.v[2]);
+            u = div_r((real)compp(po, a0) - n.v[0], n.v[1] - n.v[0]);
+            v = div_r((real)compp(po, a1) - n.v[2], n.v[3] - n.v[2]);
         }
-        front_face = dot(outward, od) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
+        front_face = dot(outward, odf) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
         normal = front_face ? outward : -outward;
         p = po;
         if (ob.xform & XF_ROTATE) {  // Rotate::hit, transforms.rs:134-139 (quirk Q10: world normal vs object-space ray)
             p = rotate_fwd(ob, p);
-            const V3 nw = rotate_fwd(ob, normal);
-            front_face = dot(nw, od) < (real)0;
+            const V3 nw = to_v3(rotate_fwd(ob, to_p3(normal)));
+            front_face = dot(nw, odf) < (real)0;
             normal = front_face ? nw : -nw;
         }
         if (ob.xform & XF_TRANSLATE) {  // Translate::hit, transforms.rs:36-39 (moved_r.dir == r.dir)
-            p = p + ld3(ob.off);
-            front_face = dot(normal, d) < (real)0;
+            p = p + mkp((double)ob.off[0], (double)ob.off[1], (double)ob.off[2]);
+            front_face = dot(normal, dw) < (real)0;
             normal = front_face ? normal : -normal;
         }
     }
+    const V3 pf = to_v3(p);
     const DMaterial<real> m = S.materials[mat_id];
     const int mk_kind = m.kind & 0xFF;
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
@@ -503,16 +549,16 @@ DEV bool shade(const Scene& S, const HitRec& rec, V3& o, V3& d, V3& thr, V3& emi
         V3 dir = normal + s;
         const real eps = (real)1e-8;
         if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
-        thr = thr * texture_value(S, m.tex, u, v, p);
-        o = p; d = dir;
+        thr = thr * texture_value(S, m.tex, u, v, pf);
+        o = p; d = to_p3(dir);
         return true;
     }
     if (mk_kind == MLRT_MAT_METAL) {  // materials.rs:51-61 (quirk Q7)
-        const V3 reflected = reflect(unit(d), normal);
+        const V3 reflected = reflect(unit(dw), normal);
         const V3 dir = reflected + m.param * random_in_unit_sphere(g, key);
         if (dot(dir, normal) > (real)0) {
             thr = thr * ld3(m.albedo);
-            o = p; d = dir;
+            o = p; d = to_p3(dir);
             return true;
         }
         emitted = mk(0, 0, 0);  // Material::emit default, materials.rs:9-11
@@ -520,47 +566,51 @@ DEV bool shade(const Scene& S, const HitRec& rec, V3& o, V3& d, V3& thr, V3& emi
     }
     if (mk_kind == MLRT_MAT_DIELECTRIC) {  // materials.rs:88-106 (quirk Q8)
         const real refraction_ratio = !front_face ? m.param : div_r((real)1, m.param);
-        const V3 unit_direction = unit(d);
+        const V3 unit_direction = unit(dw);
         const real cos_theta = min_r(dot(normal, -unit_direction), (real)1);
         const real sin_theta = sqrt_r((real)1 - cos_theta * cos_theta);
         const bool cannot_refract = refraction_ratio * sin_theta > (real)1;
         V3 dir;
-        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_range(g, key, (real)0, (real)1)) dir = reflect(unit_direction, normal);
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > u01(rng_next(g, key))) dir = reflect(unit_direction, normal);
         else dir = refract(unit_direction, normal, refraction_ratio);
-        o = p; d = dir;
+        o = p; d = to_p3(dir);
         return true;
     }
     if (mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
         const V3 dir = random_in_unit_sphere(g, key);
-        thr = thr * texture_value(S, m.tex, u, v, p);
-        o = p; d = dir;
+        thr = thr * texture_value(S, m.tex, u, v, pf);
+        o = p; d = to_p3(dir);
         return true;
     }
-    emitted = texture_value(S, m.tex, u, v, p);  // DiffuseLight, materials.rs:119-127
+    emitted = texture_value(S, m.tex, u, v, pf);  // DiffuseLight, materials.rs:119-127
     return false;
 }
 
-DEV V3 background_color(const KParams<real>& P, V3 d) {  // raytrace.rs:29-35, 44-48
+DEV V3 background_color(const KParams<real>& P, P3 d) {  // raytrace.rs:29-35, 44-48
     if (P.bg_kind == MLRT_BG_BLACK) return mk(0, 0, 0);
-    const V3 ud = unit(d);
+    const V3 ud = unit(to_v3(d));
     const real t = (real)0.5 * (ud.y + (real)1);
     return ((real)1 - t) * ld3(P.bg_bottom) + t * ld3(P.bg_top);
 }
 
-DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j, V3& o, V3& d) {  // raytrace.rs:191-193, camera.rs:40-48
-    const real s = div_r((real)i + rng_range(g, key, (real)0, (real)1), (real)P.width - (real)1);
-    const real t = div_r((real)j + rng_range(g, key, (real)0, (real)1), (real)P.height - (real)1);
-    real a, b;
-    for (;;) {  // random_in_unit_disk, vec.rs:45-52 (quirk Q6: drawn even when lens_radius == 0)
-        a = rng_range(g, key, (real)-1, (real)1);
-        b = rng_range(g, key, (real)-1, (real)1);
-        if (a * a + b * b < (real)1) break;
+// raytrace.rs:191-193 + Camera::get_ray, camera.rs:40-48, in f64 in both builds: the uniforms are 24-bit values
+// exact in either precision, so the primary ray is bit-identical to the oracle's.  A fresh sample starts at draw 0,
+// hence its first four draws (u, v and the first lens pair) are exactly Philox block 0: no refill branch.
+DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
+    rng_fill(g, key, 0u);
+    g.draw = 4u;
+    const double s = ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
+    const double t = ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
+    double a = u01d(g.b2) * 2.0 + -1.0, b = u01d(g.b3) * 2.0 + -1.0;
+    while (!(a * a + b * b < 1.0)) {  // random_in_unit_disk, vec.rs:45-52 (quirk Q6: drawn even when lens_radius == 0)
+        a = u01d(rng_next(g, key)) * 2.0 + -1.0;
+        b = u01d(rng_next(g, key)) * 2.0 + -1.0;
     }
-    const real rdx = P.lens_radius * a, rdy = P.lens_radius * b;
-    const V3 offset = ld3(P.cam_u) * rdx + ld3(P.cam_v) * rdy;
-    const V3 origin = ld3(P.cam_origin);
+    const double rdx = P.lens_radius * a, rdy = P.lens_radius * b;
+    const P3 offset = ld3p(P.cam_u) * rdx + ld3p(P.cam_v) * rdy;
+    const P3 origin = ld3p(P.cam_origin);
     o = origin + offset;
-    d = ld3(P.cam_llc) + s * ld3(P.cam_horizontal) + t * ld3(P.cam_vertical) - origin - offset;
+    d = ld3p(P.cam_llc) + s * ld3p(P.cam_horizontal) + t * ld3p(P.cam_vertical) - origin - offset;
 }
 
 // 2^-32 fixed point; integer accumulation is order independent.  NaN/negative radiance cannot occur on this
@@ -624,7 +674,8 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
         int next = 0;                  // wave-uniform queue head
         bool alive = false;
         int pix = 0, depth = 0;
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
+        P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
+        V3 thr = mk(1, 1, 1);
         Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
         for (;;) {
@@ -638,7 +689,6 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                     const int s = q - pix * spp;
                     g.pixel = (uint32_t)(j * P.width + x0 + pix);
                     g.sample = (uint32_t)s;
-                    g.draw = 0u;
                     gen_camera_ray(P, g, key, x0 + pix, j, o, d);
                     thr = mk(1, 1, 1);
                     depth = P.max_depth;

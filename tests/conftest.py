@@ -17,6 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def mlrt():
     """The product package (ctypes binding of libmlrt_hip.so)."""
+    # PyTorch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's): in a process that uses both, torch's
+    # runtime must be the one that gets loaded, so import torch before libmlrt_hip.so pulls in the system one.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     mod = importlib.import_module("mu-lambda-raytracer_amd")
     if not os.path.exists(mod.LIB_PATH):
         importlib.import_module("mu-lambda-raytracer_amd.build").build()

@@ -1,0 +1,31 @@
+"""Perf exploration helper (not a test): kernel time of the bench workloads for the library in $MLRT_LIB."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("mu-lambda-raytracer_amd")
+import torch
+
+def run(name, W, aspect, spp, reps=3, aperture=0.0, focus=None):
+    earth = pkg.load_earthmap() if name in ("earth", "final_scene") else None
+    w = pkg.World(name, 42, earth)
+    H = pkg.image_height(W, aspect)
+    cam = pkg.default_camera(w, aspect, aperture, focus)
+    params = pkg.make_params(w, W, H, spp)
+    r = pkg.Renderer(w, cam, params)
+    d_rgb = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
+    ms = []
+    for _ in range(reps + 1):
+        r.render_device(None, H, d_rgb.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        ms.append(r.last_kernel_ms())
+    ms = ms[1:]
+    print("%-40s %-12s %4dx%-4d spp %-5d kernel ms min %.1f med %.1f -> %.0f Msamples/s  %s" % (os.path.basename(pkg.LIB_PATH), name, W, H, spp, min(ms), float(np.median(ms)),
+          W * H * spp / min(ms) / 1e3, r.info()), flush=True)
+    r.close(); w.close()
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c4"]
+    if "c2" in which: run("random", 1200, 1.5, 500)
+    if "c3" in which: run("random", 1200, 1.5, 500, aperture=0.1, focus=10.0)
+    if "c4" in which: run("final_scene", 800, 1.0, 200)
