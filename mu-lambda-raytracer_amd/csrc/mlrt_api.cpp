@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -42,13 +44,12 @@ struct Fail {
 template <typename R>
 struct Packed {
     std::vector<DNode<R>> nodes;
-    std::vector<DObject<R>> objects;
     std::vector<DMaterial<R>> materials;
     std::vector<DTexture<R>> textures;
     std::vector<R> perlin_vec;
     std::vector<uint16_t> perlin_perm;
     std::vector<unsigned char> blob;
-    int32_t off_nodes = 0, off_objects = 0, off_materials = 0, off_textures = 0, off_perlin_vec = 0, off_perlin_perm = 0;
+    int32_t off_nodes = 0, off_materials = 0, off_textures = 0, off_perlin_vec = 0, off_perlin_perm = 0;
 };
 
 void validate(const mlrt_scene& s) {
@@ -129,19 +130,52 @@ DNode<R> leaf_node(const mlrt_scene& s, const mlrt_prim_ref& p) {
     return n;
 }
 
-// Depth-first emission with skip links.  `budget` guards against cyclic child references.
+// Box bounds in the entry's precision, rounded OUTWARD so the f32 slab test stays conservative.
 template <typename R>
-void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out, int& budget) {
+R round_down(double x) {
+    R f = (R)x;
+    if (std::getenv("MLRT_NO_OUTWARD")) return f;
+    if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<R>::infinity());
+    return f;
+}
+template <typename R>
+R round_up(double x) {
+    R f = (R)x;
+    if (std::getenv("MLRT_NO_OUTWARD")) return f;
+    if ((double)f < x) f = std::nextafter(f, std::numeric_limits<R>::infinity());
+    return f;
+}
+
+// Depth-first emission with skip links.  `budget` guards against cyclic child references.  With `wrap_leaves` a
+// sphere leaf is preceded by an inner entry holding the sphere's own bounds (skip = past the sphere): a ray that
+// misses those bounds cannot hit the sphere, so the closest hit is unchanged while most f64 sphere tests are culled.
+template <typename R>
+void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out, int& budget, bool wrap_leaves) {
     MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
-    if (child < 0) { out.push_back(leaf_node<R>(s, s.prim_refs[~child])); return; }
+    if (child < 0) {
+        const mlrt_prim_ref& p = s.prim_refs[~child];
+        if (wrap_leaves && p.kind == MLRT_PRIM_SPHERE) {
+            const mlrt_sphere& sp = s.spheres[p.index];
+            DNode<R> w{};
+            for (int k = 0; k < 3; k++) {
+                w.v[k] = round_down<R>(std::fmin(sp.center[k] - sp.radius, sp.center[k] + sp.radius));
+                w.v[3 + k] = round_up<R>(std::fmax(sp.center[k] - sp.radius, sp.center[k] + sp.radius));
+            }
+            w.tag = TAG_INNER;
+            w.link = (int32_t)out.size() + 2;
+            out.push_back(w);
+        }
+        out.push_back(leaf_node<R>(s, p));
+        return;
+    }
     const mlrt_bvh_node& src = s.bvh_nodes[child];
     const size_t me = out.size();
     DNode<R> n{};
-    for (int k = 0; k < 3; k++) { n.v[k] = (R)src.bounds_min[k]; n.v[3 + k] = (R)src.bounds_max[k]; }
+    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(src.bounds_min[k]); n.v[3 + k] = round_up<R>(src.bounds_max[k]); }
     n.tag = TAG_INNER;
     out.push_back(n);
-    emit_subtree<R>(s, src.left, out, budget);
-    emit_subtree<R>(s, src.right, out, budget);
+    emit_subtree<R>(s, src.left, out, budget, wrap_leaves);
+    emit_subtree<R>(s, src.right, out, budget, wrap_leaves);
     out[me].link = (int32_t)out.size();
 }
 
@@ -155,13 +189,20 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
 }
 
 template <typename R>
-Packed<R> pack(const mlrt_scene& s) {
+Packed<R> pack(const mlrt_scene& s, bool wrap_leaves) {
     Packed<R> P;
     for (int i = 0; i < s.n_objects; i++) {
         const mlrt_object& src = s.objects[i];
-        DObject<R> o{};
-        o.kind = src.kind;
-        o.node_begin = (int32_t)P.nodes.size();
+        const bool xf = src.transform >= 0 && (s.transforms[src.transform].has_translate || s.transforms[src.transform].has_rotate);
+        if (xf) {  // Translate(offset, Rotate(axis, angle, .)) opens: the cursor's ray moves to object space
+            const mlrt_transform& t = s.transforms[src.transform];
+            DNode<R> e{};
+            e.v[0] = (R)(t.has_rotate ? t.sin_theta : 0.0);
+            e.v[1] = (R)(t.has_rotate ? t.cos_theta : 1.0);
+            for (int k = 0; k < 3; k++) e.v[2 + k] = (R)(t.has_translate ? t.offset[k] : 0.0);
+            e.tag = TAG_XFORM | ((t.has_translate ? XF_TRANSLATE : 0) << 4) | ((t.has_rotate ? XF_ROTATE : 0) << 4) | ((t.has_rotate ? t.axis : 0) << 8);
+            P.nodes.push_back(e);
+        }
         if (src.kind == MLRT_OBJ_BVH) {
             const int32_t root = s.bvhs[src.bvh].root;
             if (root == MLRT_BVH_EMPTY) {
@@ -170,21 +211,23 @@ Packed<R> pack(const mlrt_scene& s) {
                 P.nodes.push_back(e);
             } else {
                 int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
-                emit_subtree<R>(s, root, P.nodes, budget);
+                emit_subtree<R>(s, root, P.nodes, budget, wrap_leaves);
             }
-        } else {
+        } else if (src.kind == MLRT_OBJ_PRIM) {
+            P.nodes.push_back(leaf_node<R>(s, src.prim));
+        } else {  // ConstantMedium: the medium entry, then its boundary primitive
+            DNode<R> e{};
+            e.v[0] = (R)src.neg_inv_density;
+            e.link = src.phase_material;
+            e.tag = TAG_MEDIUM;
+            P.nodes.push_back(e);
             P.nodes.push_back(leaf_node<R>(s, src.prim));
         }
-        o.node_end = (int32_t)P.nodes.size();
-        o.sin_t = 0; o.cos_t = 1;
-        if (src.transform >= 0) {
-            const mlrt_transform& t = s.transforms[src.transform];
-            if (t.has_translate) { o.xform |= XF_TRANSLATE; for (int k = 0; k < 3; k++) o.off[k] = (R)t.offset[k]; }
-            if (t.has_rotate) { o.xform |= XF_ROTATE | (t.axis << 4); o.sin_t = (R)t.sin_theta; o.cos_t = (R)t.cos_theta; }
+        if (xf) {
+            DNode<R> e{};
+            e.tag = TAG_XFORM_END;
+            P.nodes.push_back(e);
         }
-        o.neg_inv_density = (R)src.neg_inv_density;
-        o.phase_mat = src.phase_material;
-        P.objects.push_back(o);
     }
     for (int i = 0; i < s.n_materials; i++) {
         const mlrt_material& m = s.materials[i];
@@ -212,7 +255,6 @@ Packed<R> pack(const mlrt_scene& s) {
         }
     }
     P.off_nodes = append(P.blob, P.nodes);
-    P.off_objects = append(P.blob, P.objects);
     P.off_materials = append(P.blob, P.materials);
     P.off_textures = append(P.blob, P.textures);
     P.off_perlin_vec = append(P.blob, P.perlin_vec);
@@ -231,8 +273,8 @@ struct mlrt_context {
     int32_t n_cus = 0;
     unsigned char* d_blob = nullptr;
     int32_t blob_bytes = 0;
-    int32_t off[6] = {0, 0, 0, 0, 0, 0};
-    int32_t n_objects = 0;
+    int32_t off[5] = {0, 0, 0, 0, 0};
+    int32_t n_nodes = 0;
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
@@ -261,9 +303,9 @@ template <typename R>
 void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb,
                  double* d_accum, KParams<R>& K) {
     K.blob = c->d_blob; K.blob_bytes = c->blob_bytes;
-    K.off_nodes = c->off[0]; K.off_objects = c->off[1]; K.off_materials = c->off[2]; K.off_textures = c->off[3];
-    K.off_perlin_vec = c->off[4]; K.off_perlin_perm = c->off[5];
-    K.n_objects = c->n_objects;
+    K.off_nodes = c->off[0]; K.off_materials = c->off[1]; K.off_textures = c->off[2];
+    K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
+    K.n_nodes = c->n_nodes;
     K.images = c->d_images;
     for (int k = 0; k < 3; k++) {
         K.cam_origin[k] = cam->origin[k]; K.cam_llc[k] = cam->lower_left_corner[k];
@@ -284,6 +326,8 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.n_tiles = K.tiles_per_row * n_rows;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
+    K.debug_pixel = -1; K.debug_sample = -1;
+    if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }
 }
 
 void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) {
@@ -369,20 +413,21 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         c->n_cus = prop.multiProcessorCount;
         std::vector<unsigned char> blob;
         if (precision == MLRT_PRECISION_FP32) {
-            Packed<float> P = pack<float>(*scene);
+            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr);
             blob.swap(P.blob);
-            const int32_t o[6] = {P.off_nodes, P.off_objects, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
+            const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
+            c->n_nodes = (int32_t)P.nodes.size();
             c->block_threads = mlrt_block_threads_f32();
         } else {
-            Packed<double> P = pack<double>(*scene);
+            Packed<double> P = pack<double>(*scene, false);
             blob.swap(P.blob);
-            const int32_t o[6] = {P.off_nodes, P.off_objects, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
+            const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
+            c->n_nodes = (int32_t)P.nodes.size();
             c->block_threads = mlrt_block_threads_f64();
         }
         c->blob_bytes = (int32_t)blob.size();
-        c->n_objects = scene->n_objects;
         MLRT_HIP(hipMalloc(&c->d_blob, blob.size()));
         MLRT_HIP(hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
         std::vector<DImage> images;
@@ -405,7 +450,7 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         const int waves = c->block_threads / 64;
         const size_t acc = (size_t)waves * (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64());
         const size_t lds_limit = 160 * 1024;
-        c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit;
+        c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit && std::getenv("MLRT_NO_LDS") == nullptr;
         c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;
         const int occ = precision == MLRT_PRECISION_FP32 ? mlrt_occupancy_f32(c->lds_scene, c->dyn_lds) : mlrt_occupancy_f64(c->lds_scene, c->dyn_lds);
         c->blocks_per_cu = occ > 0 ? occ : 1;

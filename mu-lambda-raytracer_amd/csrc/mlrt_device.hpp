@@ -3,49 +3,46 @@
 // The packed scene is ONE position-independent blob (indices, no pointers) so that it can be uploaded to HBM
 // once and staged into LDS by every workgroup with coalesced 16-byte loads:
 //
-//   [ nodes | objects | materials | textures | perlin ranvec | perlin perm ]
+//   [ entries | materials | textures | perlin ranvec | perlin perm ]
 //
-// nodes: every BVH of the scene linearised in depth-first (pre-order) order with "skip" links - a threaded
-// BVH.  Traversal is stackless: an inner node whose box is hit continues at node+1, otherwise at its skip
-// link; a leaf carries its primitive INLINE (sphere / box / rect parameters in the 6 reals of the node), so a
-// primitive test needs no second dependent load.  Because the order is the reference's own
-// left-then-right recursion (bhv.rs:147-165) with the hit distance shrinking as leaves are accepted, the
-// threaded walk performs exactly the box and primitive tests the reference performs, in the same order.
-// Leaves are never box-tested, as in the reference (quirk Q4).
+// entries: the WHOLE world as one linear, threaded array that a ray walks front to back with a single cursor and
+// no stack.  The top-level HittableList (hittable.rs:37-69) becomes the order of the entries; every BVH
+// (bhv.rs:109-112) is linearised in place in depth-first (pre-order) order with "skip" links: an inner node whose
+// box is hit continues at entry+1, otherwise at its skip link; a leaf carries its primitive INLINE (sphere / box /
+// rect parameters in the 6 reals of the entry), so a primitive test needs no second dependent load.  Because the
+// order is the reference's own left-then-right recursion (bhv.rs:147-165) and list order, with the hit distance
+// shrinking as primitives are accepted, the walk performs exactly the box and primitive tests the reference
+// performs, in the same order (so ConstantMedium draws happen under the same conditions, quirk Q9).  Leaves are
+// not box-tested, as in the reference (quirk Q4), unless the packer wraps them (fast build option, same result).
+// Translate/Rotate wrappers (transforms.rs) become XFORM ... XFORM_END brackets that switch the cursor's ray
+// between world and object space; a ConstantMedium (volumes.rs) is a MEDIUM entry followed by its boundary.
 #pragma once
 #include <cstdint>
 
 namespace mlrt {
 
-enum : int32_t { TAG_INNER = 0, TAG_SPHERE = 1, TAG_BOX = 2, TAG_RECT = 3, TAG_EMPTY = 4, TAG_KIND_MASK = 0xF };
-// TAG_RECT nodes carry their axes in the tag: (a0 << 4) | (a1 << 6) | (aplane << 8)
+enum : int32_t {
+    TAG_INNER = 0, TAG_SPHERE = 1, TAG_BOX = 2, TAG_RECT = 3, TAG_EMPTY = 4, TAG_MEDIUM = 5, TAG_XFORM = 6, TAG_XFORM_END = 7,
+    TAG_KIND_MASK = 0xF
+};
+// TAG_RECT entries carry their axes in the tag: (a0 << 4) | (a1 << 6) | (aplane << 8)
+// TAG_XFORM entries carry XF_TRANSLATE << 4 | XF_ROTATE << 4 | axis << 8
+enum : int32_t { XF_TRANSLATE = 1, XF_ROTATE = 2 };
 
 template <typename R>
 struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
-    // inner : v = bounds min xyz, max xyz             link = skip (absolute node index)
-    // sphere: v = cx, cy, cz, radius                  link = material
-    // box   : v = min xyz, max xyz (shapes.rs Block)  link = material
-    // rect  : v = a0_v0, a0_v1, a1_v0, a1_v1, plane   link = material
+    // inner    : v = bounds min xyz, max xyz              link = skip (absolute entry index)
+    // sphere   : v = cx, cy, cz, radius                   link = material
+    // box      : v = min xyz, max xyz (shapes.rs Block)   link = material
+    // rect     : v = a0_v0, a0_v1, a1_v0, a1_v1, plane    link = material
+    // medium   : v = neg_inv_density                      link = phase (Isotropic) material; boundary = next entry
+    // xform    : v = sin, cos, offset xyz                 (Translate(offset, Rotate(axis, angle, .)))
     R v[6];
     int32_t link;
     int32_t tag;
 };
-static_assert(sizeof(DNode<float>) == 32, "f32 node must be 32 bytes (two ds_read_b128)");
-static_assert(sizeof(DNode<double>) == 64, "f64 node is one 64-byte line");
-
-enum : int32_t { XF_TRANSLATE = 1, XF_ROTATE = 2 };  // xform bits; rotation axis in bits 4..5
-
-template <typename R>
-struct DObject {  // one entry of the top-level HittableList (hittable.rs:37-69)
-    int32_t kind;        // MLRT_OBJ_PRIM / MLRT_OBJ_BVH / MLRT_OBJ_MEDIUM
-    int32_t node_begin;  // PRIM/MEDIUM: the leaf node; BVH: first node
-    int32_t node_end;    // BVH: one past the last node
-    int32_t xform;       // XF_* | axis << 4
-    R sin_t, cos_t, off[3];
-    R neg_inv_density;  // MEDIUM
-    int32_t phase_mat;  // MEDIUM
-    int32_t _pad;
-};
+static_assert(sizeof(DNode<float>) == 32, "f32 entry must be 32 bytes (two ds_read_b128)");
+static_assert(sizeof(DNode<double>) == 64, "f64 entry is one 64-byte line");
 
 enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8 };  // set on the material kind when its texture chain samples an image
 
@@ -73,8 +70,8 @@ template <typename R>
 struct KParams {
     const unsigned char* blob;  // packed scene in HBM
     int32_t blob_bytes;
-    int32_t off_nodes, off_objects, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
-    int32_t n_objects;
+    int32_t off_nodes, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
+    int32_t n_nodes;
     const DImage* images;
     // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
@@ -89,6 +86,7 @@ struct KParams {
     int32_t* rgb_out;     // [n_rows][W][3]
     double* accum_out;    // optional [n_rows][W][3]
     unsigned int* tile_counter;
+    int32_t debug_pixel, debug_sample;  // >= 0: printf the path of that (pixel, sample) from the kernel (MLRT_DEBUG_PIXEL=pixel,sample)
 };
 
 }  // namespace mlrt

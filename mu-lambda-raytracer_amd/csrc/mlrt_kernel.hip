@@ -96,6 +96,16 @@ DEV V3 axis_vec(int i, real s) { return mk(i == 0 ? s : (real)0, i == 1 ? s : (r
 struct P3 {
     double x, y, z;
 };
+// a*b + c for the f64 geometry code.  The fast build fuses EXPLICITLY and pins the compiler's own contraction off
+// in the functions that use it: the reference relies on evaluating the same quadratic twice giving the identical
+// root (a ConstantMedium boundary that is a clone of a listed sphere, worlds.rs:428-430 -> volumes.rs:36 `h1.t >=
+// h2.t`), and with -ffp-contract=fast two inlined copies may be fused differently and differ in the last bit.
+// The parity build keeps the reference's separate multiply and add.
+DEV double dfma(double a, double b, double c) {
+#pragma clang fp contract(off)
+    if (sizeof(MLRT_REAL) == 4) return __builtin_fma(a, b, c);
+    return a * b + c;
+}
 DEV P3 mkp(double x, double y, double z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEV P3 to_p3(V3 a) { return mkp((double)a.x, (double)a.y, (double)a.z); }
 DEV V3 to_v3(P3 a) { return mk((real)a.x, (real)a.y, (real)a.z); }
@@ -168,8 +178,7 @@ DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {                // vec.rs:23-3
 
 // ---------------------------------------------------------------------------------------------- scene view
 struct Scene {
-    const DNode<real>* nodes;
-    const DObject<real>* objects;
+    const DNode<real>* nodes;       // the linear threaded entry array (see mlrt_device.hpp)
     const DMaterial<real>* materials;
     const DTexture<real>* textures;
     const real* perlin_vec;         // [tables][1024][3]
@@ -177,43 +186,86 @@ struct Scene {
     const DImage* images;           // HBM (L2-resident)
 };
 
-// A ray as the intersection routines see it: the f64 geometry state plus (fast build) its f32 image for the slabs.
+// What the cheap per-step tests need of the ray in the current (world or object) space.
+struct SlabRay {
+    V3 of, invd;   // fast build: (float)origin and 1/(float)direction; parity build: origin and direction
+};
+// The f64 ray for the primitive tests.
 struct Ray {
-    P3 o, d;       // f64, object space of the object being tested
-    V3 of, invd;   // fast build: (float)o and 1/(float)d
+    P3 o, d;
     double a;      // |d|^2
     double inv_a;  // fast build: 1/|d|^2
 };
-DEV void finish_ray(Ray& r) {
-    r.a = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
+
+// Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132), in f64
+DEV P3 rotate_back(const DNode<real>& xf, P3 v) {
+#pragma clang fp contract(off)
+    const int a1 = (xf.tag >> 8) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
+    const double sin_t = (double)xf.v[0], cos_t = (double)xf.v[1];
+    const double v0 = compp(v, a0), v2 = compp(v, a2);
+    const double n0 = dfma(cos_t, v0, -(sin_t * v2));
+    const double n2 = dfma(sin_t, v0, cos_t * v2);
+    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+}
+DEV P3 rotate_fwd(const DNode<real>& xf, P3 v) {  // transforms.rs:116-124
+#pragma clang fp contract(off)
+    const int a1 = (xf.tag >> 8) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
+    const double sin_t = (double)xf.v[0], cos_t = (double)xf.v[1];
+    const double v0 = compp(v, a0), v2 = compp(v, a2);
+    const double n0 = dfma(cos_t, v0, sin_t * v2);
+    const double n2 = dfma(-sin_t, v0, cos_t * v2);
+    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
+}
+DEV bool xf_translates(const DNode<real>& xf) { return ((xf.tag >> 4) & XF_TRANSLATE) != 0; }
+DEV bool xf_rotates(const DNode<real>& xf) { return ((xf.tag >> 4) & XF_ROTATE) != 0; }
+DEV void to_object(const DNode<real>& xf, P3& o, P3& d) {
+#pragma clang fp contract(off)
+    if (xf_translates(xf)) o = o - mkp((double)xf.v[2], (double)xf.v[3], (double)xf.v[4]);
+    if (xf_rotates(xf)) { o = rotate_back(xf, o); d = rotate_back(xf, d); }
+}
+// The ray in the space of the bracket `xf` (entry index, -1 = world).
+DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
+#pragma clang fp contract(off)
+    Ray r;
+    r.o = o; r.d = d;
+    if (xf >= 0) to_object(S.nodes[xf], r.o, r.d);
+    r.a = dfma(r.d.z, r.d.z, dfma(r.d.y, r.d.y, r.d.x * r.d.x));  // length_squared: x*x + y*y + z*z
     if (kFast) {
-        r.of = to_v3(r.o);
-        r.invd = mk(fast_rcp((real)r.d.x), fast_rcp((real)r.d.y), fast_rcp((real)r.d.z));
-        // 1/|d|^2 to f64 accuracy: f32 seed + 2 Newton steps (no f64 divide in the hot loop)
+        // 1/|d|^2 to f64 accuracy: f32 seed + 2 Newton steps (no f64 divide in the hot path)
         double x = (double)__builtin_amdgcn_rcpf((float)r.a);
-        x = x * (2.0 - r.a * x);
-        x = x * (2.0 - r.a * x);
+        x = x * dfma(-r.a, x, 2.0);
+        x = x * dfma(-r.a, x, 2.0);
         r.inv_a = x;
     } else {
-        r.of = to_v3(r.o);
-        r.invd = to_v3(r.d);
         r.inv_a = 0.0;
     }
+    return r;
+}
+DEV SlabRay slab_ray(const Ray& r) {
+    SlabRay q;
+    q.of = to_v3(r.o);
+    if (kFast) q.invd = mk(fast_rcp((real)r.d.x), fast_rcp((real)r.d.y), fast_rcp((real)r.d.z));
+    else q.invd = to_v3(r.d);
+    return q;
 }
 
 // AABB::hit, bhv.rs:29-42 (quirk Q5).  Evaluating the three slabs and testing once equals the reference's
 // per-axis early exit because the interval only shrinks.
-DEV bool slab_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax) {
+DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) {
     real t0, t1;
     if (kFast) { t0 = (n.v[0] - r.of.x) * r.invd.x; t1 = (n.v[3] - r.of.x) * r.invd.x; }
-    else { t0 = (n.v[0] - (real)r.o.x) / (real)r.d.x; t1 = (n.v[3] - (real)r.o.x) / (real)r.d.x; }
+    else { t0 = (n.v[0] - r.of.x) / r.invd.x; t1 = (n.v[3] - r.of.x) / r.invd.x; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
     if (kFast) { t0 = (n.v[1] - r.of.y) * r.invd.y; t1 = (n.v[4] - r.of.y) * r.invd.y; }
-    else { t0 = (n.v[1] - (real)r.o.y) / (real)r.d.y; t1 = (n.v[4] - (real)r.o.y) / (real)r.d.y; }
+    else { t0 = (n.v[1] - r.of.y) / r.invd.y; t1 = (n.v[4] - r.of.y) / r.invd.y; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
     if (kFast) { t0 = (n.v[2] - r.of.z) * r.invd.z; t1 = (n.v[5] - r.of.z) * r.invd.z; }
-    else { t0 = (n.v[2] - (real)r.o.z) / (real)r.d.z; t1 = (n.v[5] - (real)r.o.z) / (real)r.d.z; }
+    else { t0 = (n.v[2] - r.of.z) / r.invd.z; t1 = (n.v[5] - r.of.z) / r.invd.z; }
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
+    // fast build: 2-ulp slack on the far bound keeps the f32 cull conservative against the f64 hit distance
+#ifndef MLRT_NO_ROBUST
+    if (kFast) return !(tmax * (real)1.0000003 <= tmin);
+#endif
     return !(tmax <= tmin);
 }
 
@@ -221,11 +273,12 @@ DEV bool slab_hit(const DNode<real>& n, const Ray& r, real tmin, real tmax) {
 // sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
 // the f32 rate, so this is affordable; the fast build avoids the f64 divide and square-root sequences.
 DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+#pragma clang fp contract(off)
     const double ocx = r.o.x - (double)n.v[0], ocy = r.o.y - (double)n.v[1], ocz = r.o.z - (double)n.v[2];
     const double radius = (double)n.v[3];
-    const double half_b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
-    const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
-    const double discriminant = half_b * half_b - r.a * c;
+    const double half_b = dfma(ocz, r.d.z, dfma(ocy, r.d.y, ocx * r.d.x));           // oc.dot(dir)
+    const double c = dfma(ocz, ocz, dfma(ocy, ocy, ocx * ocx)) - radius * radius;   // oc.length_squared() - r*r
+    const double discriminant = dfma(half_b, half_b, -(r.a * c));                   // half_b*half_b - a*c
     if (discriminant < 0.0) return false;
     double sqrtd, root;
     if (kFast) {
@@ -234,9 +287,9 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
             sqrtd = 0.0;
         } else {
             double y = (double)__builtin_amdgcn_rsqf((float)discriminant);
-            y = y * (1.5 - 0.5 * discriminant * y * y);
+            y = y * dfma(-0.5 * discriminant, y * y, 1.5);
             double s = discriminant * y;
-            s = s + 0.5 * y * (discriminant - s * s);
+            s = dfma(0.5 * y, dfma(-s, s, discriminant), s);
             sqrtd = s;
         }
         root = (-half_b - sqrtd) * r.inv_a;
@@ -259,13 +312,14 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
 // Block::hit = HittableList of six AARects (shapes.rs:172-192, hittable.rs:53-69): the nearest face hit inside
 // [tmin, tmax].  The faces a line can hit inside their rectangles are the slab entry and exit faces, so the six
 // rect tests collapse into one slab evaluation with the same t = (k - o)/d per face.
-DEV bool box_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& axis_out) {
+DEV bool box_hit(const DNode<real>& n, const SlabRay& r, double tmin, double tmax, double& t_out, int& axis_out) {
     real lo[3], hi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
+        const real oa = comp(r.of, a), ia = comp(r.invd, a);
         real t0, t1;
-        if (kFast) { const real oa = comp(r.of, a), ia = comp(r.invd, a); t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
-        else { const real oa = (real)compp(r.o, a), da = (real)compp(r.d, a); t0 = (n.v[a] - oa) / da; t1 = (n.v[3 + a] - oa) / da; }
+        if (kFast) { t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
+        else { t0 = (n.v[a] - oa) / ia; t1 = (n.v[3 + a] - oa) / ia; }
         lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
     }
     real te = lo[0]; int ae = 0;
@@ -284,10 +338,10 @@ DEV bool box_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, d
 DEV bool rect_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
     const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
     if (kFast) {
-        const real t = (n.v[4] - comp(r.of, ap)) * comp(r.invd, ap);
+        const real t = ((real)n.v[4] - (real)compp(r.o, ap)) * fast_rcp((real)compp(r.d, ap));
         if ((double)t < tmin || (double)t > tmax) return false;
-        const real a0_v = comp(r.of, a0) + t * (real)compp(r.d, a0);
-        const real a1_v = comp(r.of, a1) + t * (real)compp(r.d, a1);
+        const real a0_v = (real)compp(r.o, a0) + t * (real)compp(r.d, a0);
+        const real a1_v = (real)compp(r.o, a1) + t * (real)compp(r.d, a1);
         if (a0_v < n.v[0] || a0_v > n.v[1] || a1_v < n.v[2] || a1_v > n.v[3]) return false;
         t_out = (double)t;
         return true;
@@ -301,105 +355,63 @@ DEV bool rect_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, 
     return true;
 }
 
-DEV bool leaf_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
+DEV bool prim_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
     const int kind = n.tag & TAG_KIND_MASK;
     if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
-    if (kind == TAG_BOX) return box_hit(n, r, tmin, tmax, t_out, aux);
+    if (kind == TAG_BOX) return box_hit(n, slab_ray(r), tmin, tmax, t_out, aux);
     if (kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
     return false;  // TAG_EMPTY: shapes.rs:8-23
 }
 
-// Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132), in f64
-DEV P3 rotate_back(const DObject<real>& ob, P3 v) {
-    const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const double v0 = compp(v, a0), v2 = compp(v, a2);
-    const double n0 = (double)ob.cos_t * v0 - (double)ob.sin_t * v2;
-    const double n2 = (double)ob.sin_t * v0 + (double)ob.cos_t * v2;
-    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
-}
-DEV P3 rotate_fwd(const DObject<real>& ob, P3 v) {  // transforms.rs:116-124
-    const int a1 = (ob.xform >> 4) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const double v0 = compp(v, a0), v2 = compp(v, a2);
-    const double n0 = (double)ob.cos_t * v0 + (double)ob.sin_t * v2;
-    const double n2 = -(double)ob.sin_t * v0 + (double)ob.cos_t * v2;
-    return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
-}
-DEV void to_object(const DObject<real>& ob, P3& o, P3& d) {
-    if (ob.xform & XF_TRANSLATE) o = o - mkp((double)ob.off[0], (double)ob.off[1], (double)ob.off[2]);
-    if (ob.xform & XF_ROTATE) { o = rotate_back(ob, o); d = rotate_back(ob, d); }
-}
-DEV Ray make_ray(const DObject<real>& ob, P3 o, P3 d) {
-    Ray r;
-    r.o = o; r.d = d;
-    if (ob.xform) to_object(ob, r.o, r.d);
-    finish_ray(r);
-    return r;
-}
-
-struct HitRec {
-    double t;
-    int obj;   // index into objects
-    int node;  // leaf node index (PRIM / BVH) or -1 for a medium
-    int aux;   // box: face axis
+// The per-lane traversal cursor: one ray walking the linear entry array.
+struct Cursor {
+    int node;        // next entry to look at
+    int xf;          // entry index of the open XFORM bracket or -1 (world space)
+    double closest;  // closest_so_far (hittable.rs:56, bhv.rs:155-158)
+    int hit_node;    // entry of the closest hit so far, -1 = none
+    int hit_aux;     // box: face axis
+    int hit_xf;      // bracket the hit was found in
+    SlabRay sr;      // ray image for the slab tests in the current space
 };
 
-// HittableList::hit over the top-level objects (hittable.rs:53-69) with closest_so_far shrinking in list order.
-DEV bool world_hit(const Scene& S, int n_objects, P3 o, P3 d, Rng& g, RngKey key, HitRec& rec) {
+// Entries that are not plain box tests: primitives with f64 arithmetic, media, transform brackets.  Executed in
+// batches (see the kernel loop), so the long code below is issued for many lanes at once.
+DEV void special_entry(const Scene& S, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
     const double t_min = 0.001;  // raytrace.rs:90
-    double closest = (double)INFINITY;
-    bool any = false;
-    Ray world_ray;
-    world_ray.o = o; world_ray.d = d;
-    finish_ray(world_ray);
-    for (int k = 0; k < n_objects; k++) {
-        const DObject<real> ob = S.objects[k];
-        Ray r = world_ray;
-        if (ob.xform) r = make_ray(ob, o, d);
-        if (ob.kind == MLRT_OBJ_BVH) {
-            // Node::hit, bhv.rs:147-165, as a stackless walk of the threaded tree.  "while-while": every lane first
-            // walks inner nodes until it stands on a leaf (or is done), then the leaves are tested together, so the
-            // expensive primitive code is not issued once per inner step for a handful of lanes.
-            int node = ob.node_begin;
-            const int end = ob.node_end;
-            for (;;) {
-                DNode<real> n;
-                n.tag = TAG_EMPTY;
-                while (node < end) {
-                    n = S.nodes[node];
-                    if ((n.tag & TAG_KIND_MASK) != TAG_INNER) break;
-                    node = slab_hit(n, r, (real)t_min, (real)closest) ? node + 1 : n.link;
-                }
-                if (node >= end) break;
-                double t; int aux = 0;
-                if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = node; rec.aux = aux; any = true; }
-                node = node + 1;
-            }
-        } else if (ob.kind == MLRT_OBJ_PRIM) {
-            const DNode<real> n = S.nodes[ob.node_begin];
-            double t; int aux = 0;
-            if (leaf_hit(n, r, t_min, closest, t, aux)) { closest = t; rec.t = t; rec.obj = k; rec.node = ob.node_begin; rec.aux = aux; any = true; }
-        } else {
-            // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
-            const DNode<real> n = S.nodes[ob.node_begin];
-            double t1, t2; int aux = 0;
-            if (leaf_hit(n, r, -(double)INFINITY, (double)INFINITY, t1, aux) && leaf_hit(n, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
-                t1 = fmax(t1, t_min);
-                t2 = fmin(t2, closest);
-                if (t1 < t2) {
-                    t1 = fmax(t1, 0.0);
-                    const double ray_scale = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
-                    const double distance_inside = (t2 - t1) * ray_scale;
-                    const double xi = u01d(rng_next(g, key));
-                    const double hit_distance = (double)ob.neg_inv_density * (kFast ? (double)logf((float)xi) : log(xi));
-                    if (!(hit_distance > distance_inside)) {
-                        const double t = t1 + hit_distance / ray_scale;
-                        closest = t; rec.t = t; rec.obj = k; rec.node = -1; rec.aux = 0; any = true;
-                    }
+    const DNode<real> n = S.nodes[c.node];
+    const int kind = n.tag & TAG_KIND_MASK;
+    if (kind == TAG_XFORM || kind == TAG_XFORM_END) {
+        c.xf = kind == TAG_XFORM ? c.node : -1;
+        c.sr = slab_ray(local_ray(S, c.xf, o, d));
+        c.node += 1;
+        return;
+    }
+    const Ray r = local_ray(S, c.xf, o, d);
+    if (kind == TAG_MEDIUM) {
+        // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
+        const DNode<real> boundary = S.nodes[c.node + 1];
+        double t1, t2; int aux = 0;
+        if (prim_hit(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
+            t1 = fmax(t1, t_min);
+            t2 = fmin(t2, c.closest);
+            if (t1 < t2) {
+                t1 = fmax(t1, 0.0);
+                const double ray_scale = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);  // r.dir.length() of the WORLD ray
+                const double distance_inside = (t2 - t1) * ray_scale;
+                const double xi = u01d(rng_next(g, key));
+                const double hit_distance = (double)n.v[0] * (kFast ? (double)logf((float)xi) : log(xi));
+                if (!(hit_distance > distance_inside)) {
+                    c.closest = t1 + hit_distance / ray_scale;
+                    c.hit_node = c.node; c.hit_aux = 0; c.hit_xf = c.xf;
                 }
             }
         }
+        c.node += 2;
+        return;
     }
-    return any;
+    double t; int aux = 0;
+    if (prim_hit(n, r, t_min, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+    c.node += 1;
 }
 
 // ---------------------------------------------------------------------------------------------- textures
@@ -490,35 +502,34 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
     }
 }
 
-// Evaluate the hit found by world_hit and the material response.  Returns true when the path continues with
+// Evaluate the closest hit the cursor found and the material response.  Returns true when the path continues with
 // (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
-DEV bool shade(const Scene& S, const HitRec& rec, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
-    const DObject<real> ob = S.objects[rec.obj];
+DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
+    const DNode<real> n = S.nodes[c.hit_node];
+    const int kind = n.tag & TAG_KIND_MASK;
     P3 p;
     V3 normal;
     real u = (real)0, v = (real)0;
     bool front_face = true;
-    int mat_id;
+    const int mat_id = n.link;
     const V3 dw = to_v3(d);  // world direction in shading precision
-    if (rec.node < 0) {      // volumes.rs:55-63
-        p = o + rec.t * d;
+    if (kind == TAG_MEDIUM) {  // volumes.rs:55-63
+        p = o + c.closest * d;
         normal = mk((real)1, (real)0, (real)0);
-        mat_id = ob.phase_mat;
     } else {
-        const DNode<real> n = S.nodes[rec.node];
-        mat_id = n.link;
         P3 oo = o, od = d;
-        if (ob.xform) to_object(ob, oo, od);
-        const P3 po = oo + rec.t * od;  // Ray::at
+        DNode<real> xf;
+        xf.tag = 0;
+        if (c.hit_xf >= 0) { xf = S.nodes[c.hit_xf]; to_object(xf, oo, od); }
+        const P3 po = oo + c.closest * od;  // Ray::at
         const V3 odf = to_v3(od);
-        const int kind = n.tag & TAG_KIND_MASK;
         V3 outward;
         if (kind == TAG_SPHERE) {
             if (kFast) outward = to_v3(po - mkp((double)n.v[0], (double)n.v[1], (double)n.v[2])) * fast_rcp(n.v[3]);
             else outward = mk((real)((po.x - (double)n.v[0]) / (double)n.v[3]), (real)((po.y - (double)n.v[1]) / (double)n.v[3]), (real)((po.z - (double)n.v[2]) / (double)n.v[3]));
             if (S.materials[mat_id].kind & MATFLAG_NEEDS_UV) sphere_uv(outward, u, v);
         } else if (kind == TAG_BOX) {
-            outward = axis_vec(rec.aux, (real)1);
+            outward = axis_vec(c.hit_aux, (real)1);
         } else {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);
@@ -528,16 +539,18 @@ DEV bool shade(const Scene& S, const HitRec& rec, P3& o, P3& d, V3& thr, V3& emi
         front_face = dot(outward, odf) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
         normal = front_face ? outward : -outward;
         p = po;
-        if (ob.xform & XF_ROTATE) {  // Rotate::hit, transforms.rs:134-139 (quirk Q10: world normal vs object-space ray)
-            p = rotate_fwd(ob, p);
-            const V3 nw = to_v3(rotate_fwd(ob, to_p3(normal)));
-            front_face = dot(nw, odf) < (real)0;
-            normal = front_face ? nw : -nw;
-        }
-        if (ob.xform & XF_TRANSLATE) {  // Translate::hit, transforms.rs:36-39 (moved_r.dir == r.dir)
-            p = p + mkp((double)ob.off[0], (double)ob.off[1], (double)ob.off[2]);
-            front_face = dot(normal, dw) < (real)0;
-            normal = front_face ? normal : -normal;
+        if (c.hit_xf >= 0) {
+            if (xf_rotates(xf)) {  // Rotate::hit, transforms.rs:134-139 (quirk Q10: world normal vs object-space ray)
+                p = rotate_fwd(xf, p);
+                const V3 nw = to_v3(rotate_fwd(xf, to_p3(normal)));
+                front_face = dot(nw, odf) < (real)0;
+                normal = front_face ? nw : -nw;
+            }
+            if (xf_translates(xf)) {  // Translate::hit, transforms.rs:36-39 (moved_r.dir == r.dir)
+                p = p + mkp((double)xf.v[2], (double)xf.v[3], (double)xf.v[4]);
+                front_face = dot(normal, dw) < (real)0;
+                normal = front_face ? normal : -normal;
+            }
         }
     }
     const V3 pf = to_v3(p);
@@ -622,6 +635,24 @@ DEV unsigned long long to_fixed(real c) {
     return (unsigned long long)(x * 4294967296.0 + 0.5);
 }
 
+#ifndef MLRT_BOX_SPECIAL
+#define MLRT_BOX_SPECIAL 0
+#endif
+#ifndef MLRT_T_SPECIAL
+#define MLRT_T_SPECIAL 24
+#endif
+#ifndef MLRT_T_SHADE
+#define MLRT_T_SHADE 24
+#endif
+enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3 };
+
+// The megakernel.  Every lane runs a small state machine over its current path:
+//   PH_TRAV    one cheap step per loop iteration: fetch an entry, slab-test it, follow the skip link
+//   PH_SPECIAL parked on an entry that needs the long code (f64 sphere quadratic, rect, medium, transform bracket)
+//   PH_SHADE   traversal finished: evaluate hit / background, scatter or end the path, take a new sample
+// SPECIAL and SHADE work is executed only when at least MLRT_T_* lanes are parked on it (or nothing else can
+// run), so the long divergent code paths are issued for many lanes at once while the short traversal step keeps
+// most lanes busy every iteration.  Lanes never wait for the slowest ray of a "bounce".
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<real> P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -645,7 +676,6 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
     }
     Scene S;
     S.nodes = reinterpret_cast<const DNode<real>*>(base + P.off_nodes);
-    S.objects = reinterpret_cast<const DObject<real>*>(base + P.off_objects);
     S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
     S.textures = reinterpret_cast<const DTexture<real>*>(base + P.off_textures);
     S.perlin_vec = reinterpret_cast<const real*>(base + P.off_perlin_vec);
@@ -655,6 +685,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_base + wave * kAccBytesPerWave);
     const RngKey key = {P.seed_lo, P.seed_hi};
     const int spp = P.spp;
+    const int n_nodes = P.n_nodes;
 
     for (;;) {
         // one tile per wave at a time, pulled from the global queue
@@ -672,55 +703,107 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
 
         const int total = npix * spp;  // the tile's sample queue
         int next = 0;                  // wave-uniform queue head
-        bool alive = false;
+        int phase = PH_SHADE;          // every lane starts by asking for a sample
+        bool has_path = false;
         int pix = 0, depth = 0;
         P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
         V3 thr = mk(1, 1, 1);
         Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        Cursor c;
+        c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+        c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
 
         for (;;) {
-            // path regeneration: lanes without a live path take the next queue entries in lane order
-            const unsigned long long need = __ballot(!alive);
-            if (need != 0ull && next < total) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
-                const int q = next + rank;
-                if (!alive && q < total) {
-                    pix = q / spp;
-                    const int s = q - pix * spp;
-                    g.pixel = (uint32_t)(j * P.width + x0 + pix);
-                    g.sample = (uint32_t)s;
-                    gen_camera_ray(P, g, key, x0 + pix, j, o, d);
-                    thr = mk(1, 1, 1);
-                    depth = P.max_depth;
-                    alive = true;
-                }
-                next += __popcll(need);
-            }
-            if (__ballot(alive) == 0ull) break;
-            if (alive) {
-                V3 radiance = mk(0, 0, 0);
-                bool done;
-                if (depth <= 0) {  // raytrace.rs:87-89
-                    done = true;
-                } else {
-                    HitRec rec;
-                    rec.t = 0; rec.obj = 0; rec.node = 0; rec.aux = 0;
-                    if (world_hit(S, P.n_objects, o, d, g, key, rec)) {
-                        V3 emitted = mk(0, 0, 0);
-                        if (shade(S, rec, o, d, thr, emitted, g, key)) { done = false; depth--; }
-                        else { done = true; radiance = thr * emitted; }
+            // (A) one traversal step
+            if (phase == PH_TRAV) {
+                if (c.node < n_nodes) {
+                    const DNode<real> n = S.nodes[c.node];
+                    const int kind = n.tag & TAG_KIND_MASK;
+                    if (kind == TAG_INNER) {
+                        c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
+                    } else if (kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
+                        double t; int aux = 0;
+                        if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+                        c.node += 1;
                     } else {
-                        done = true;
+                        phase = PH_SPECIAL;
+                    }
+                } else {
+                    phase = PH_SHADE;
+                }
+            }
+            const unsigned long long m_trav = __ballot(phase == PH_TRAV);
+            // (B) batched special entries
+            const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
+            if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
+                if (phase == PH_SPECIAL) {
+                    special_entry(S, c, o, d, g, key);
+                    phase = PH_TRAV;
+                }
+            }
+            // (C) batched shading, path termination and regeneration
+            const unsigned long long m_shade = __ballot(phase == PH_SHADE);
+            const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
+            if (batch) {
+                const bool mine = phase == PH_SHADE;
+                bool new_ray = false;
+                if (mine && has_path) {
+                    V3 radiance = mk(0, 0, 0);
+                    bool done = true;
+                    if (P.debug_pixel >= 0 && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
+                        printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
+                               c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
+                    if (c.hit_node >= 0) {
+                        V3 emitted = mk(0, 0, 0);
+                        if (shade(S, c, o, d, thr, emitted, g, key)) {
+                            depth--;
+                            if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
+                        } else {
+                            radiance = thr * emitted;
+                        }
+                    } else {
                         radiance = thr * background_color(P, d);
                     }
+                    if (done) {
+                        atomicAdd(&acc[pix * 3 + 0], to_fixed(radiance.x));
+                        atomicAdd(&acc[pix * 3 + 1], to_fixed(radiance.y));
+                        atomicAdd(&acc[pix * 3 + 2], to_fixed(radiance.z));
+                        has_path = false;
+                    }
                 }
-                if (done) {
-                    atomicAdd(&acc[pix * 3 + 0], to_fixed(radiance.x));
-                    atomicAdd(&acc[pix * 3 + 1], to_fixed(radiance.y));
-                    atomicAdd(&acc[pix * 3 + 2], to_fixed(radiance.z));
-                    alive = false;
+                // Path regeneration, in wave-uniform control flow so that the queue head `next` stays uniform: the
+                // batch's lanes without a path take the next queue entries in lane order.
+                const bool want = mine && !has_path;
+                const unsigned long long need = __ballot(want);
+                if (need != 0ull && next < total) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
+                    const int q = next + rank;
+                    if (want && q < total) {
+                        pix = q / spp;
+                        const int s = q - pix * spp;
+                        g.pixel = (uint32_t)(j * P.width + x0 + pix);
+                        g.sample = (uint32_t)s;
+                        gen_camera_ray(P, g, key, x0 + pix, j, o, d);
+                        thr = mk(1, 1, 1);
+                        depth = P.max_depth;
+                        has_path = depth > 0;  // max_depth == 0: the sample contributes 0 (raytrace.rs:87-89)
+                        new_ray = has_path;
+                    }
+                    next = min(total, next + (int)__popcll(need));
+                }
+                if (mine) {
+                    if (new_ray) {
+                        c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+                        Ray wr;
+                        wr.o = o; wr.d = d;
+                        c.sr = slab_ray(wr);
+                        phase = PH_TRAV;
+                    } else if (!has_path) {
+                        phase = next < total ? PH_SHADE : PH_IDLE;
+                    }
                 }
             }
+            if (__ballot(phase != PH_IDLE) == 0ull) break;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -730,9 +813,9 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
             const size_t out = ((size_t)row_k * P.width + x0) * 3 + i;
             if (P.accum_out) P.accum_out[out] = sum;
             const double scale = 1.0 / (double)spp;
-            double c = sqrt(sum * scale);
-            c = c < 0.0 ? 0.0 : (c > 0.99999999 ? 0.99999999 : c);
-            P.rgb_out[out] = (int32_t)(255.999 * c);
+            double cc = sqrt(sum * scale);
+            cc = cc < 0.0 ? 0.0 : (cc > 0.99999999 ? 0.99999999 : cc);
+            P.rgb_out[out] = (int32_t)(255.999 * cc);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
