@@ -179,6 +179,114 @@ void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out
     out[me].link = (int32_t)out.size();
 }
 
+// ---- device-side BVH quality (fast build) -------------------------------------------------------------------
+// The closest hit does not depend on the BVH's topology, so the fast build is free to replace the reference's
+// random-axis median split (bhv.rs:122-145, kept for the scene RNG replay on the host and used as-is by the parity
+// build) with a surface-area-heuristic tree over the same primitives: fewer box tests per ray, same image.
+struct Bounds {
+    double lo[3], hi[3];
+    void grow(const Bounds& b) { for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], b.lo[k]); hi[k] = std::fmax(hi[k], b.hi[k]); } }
+    double half_area() const { const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2]; return x * y + y * z + z * x; }
+};
+Bounds empty_bounds() { Bounds b; for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } return b; }
+bool prim_bounds(const mlrt_scene& s, const mlrt_prim_ref& p, Bounds& b) {
+    if (p.kind == MLRT_PRIM_SPHERE) {
+        const mlrt_sphere& sp = s.spheres[p.index];
+        for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(sp.center[k] - sp.radius, sp.center[k] + sp.radius); b.hi[k] = std::fmax(sp.center[k] - sp.radius, sp.center[k] + sp.radius); }
+        return true;
+    }
+    if (p.kind == MLRT_PRIM_BOX) {
+        const mlrt_box& bx = s.boxes[p.index];
+        for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(bx.min[k], bx.max[k]); b.hi[k] = std::fmax(bx.min[k], bx.max[k]); }
+        return true;
+    }
+    const mlrt_rect& r = s.rects[p.index];  // zero thickness: padded so the slab test (which rejects tmax <= tmin) can pass
+    const int ap = 3 - r.a0 - r.a1;
+    const double pad = 1e-4 * (1.0 + std::fabs(r.plane));
+    b.lo[r.a0] = r.a0_v0; b.hi[r.a0] = r.a0_v1; b.lo[r.a1] = r.a1_v0; b.hi[r.a1] = r.a1_v1; b.lo[ap] = r.plane - pad; b.hi[ap] = r.plane + pad;
+    return true;
+}
+template <typename R>
+DNode<R> box_entry(const Bounds& b, int32_t skip) {
+    DNode<R> n{};
+    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(b.lo[k]); n.v[3 + k] = round_up<R>(b.hi[k]); }
+    n.tag = TAG_INNER;
+    n.link = skip;
+    return n;
+}
+void collect_leaves(const mlrt_scene& s, int32_t child, std::vector<int32_t>& refs, int& budget) {
+    MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
+    if (child < 0) { refs.push_back(~child); return; }
+    collect_leaves(s, s.bvh_nodes[child].left, refs, budget);
+    collect_leaves(s, s.bvh_nodes[child].right, refs, budget);
+}
+struct SahItem {
+    int32_t ref;
+    Bounds b;
+    double c[3];
+};
+// Emits the SAH subtree over items[begin, end) in threaded order; returns its bounds.
+template <typename R>
+Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, size_t end, std::vector<DNode<R>>& out, bool wrap_leaves) {
+    const size_t n = end - begin;
+    if (n == 1) {
+        const mlrt_prim_ref& p = s.prim_refs[items[begin].ref];
+        if (wrap_leaves && p.kind != MLRT_PRIM_BOX) out.push_back(box_entry<R>(items[begin].b, (int32_t)out.size() + 2));
+        out.push_back(leaf_node<R>(s, p));
+        return items[begin].b;
+    }
+    int best_axis = 0;
+    size_t best_split = begin + n / 2;
+    double best_cost = INFINITY;
+    std::vector<double> right_area(n);
+    for (int axis = 0; axis < 3; axis++) {
+        std::sort(items.begin() + begin, items.begin() + end, [axis](const SahItem& a, const SahItem& b) { return a.c[axis] < b.c[axis]; });
+        Bounds acc = empty_bounds();
+        for (size_t i = n; i-- > 1;) { acc.grow(items[begin + i].b); right_area[i] = acc.half_area(); }
+        acc = empty_bounds();
+        for (size_t i = 1; i < n; i++) {
+            acc.grow(items[begin + i - 1].b);
+            const double cost = acc.half_area() * (double)i + right_area[i] * (double)(n - i);
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = begin + i; }
+        }
+    }
+    std::sort(items.begin() + begin, items.begin() + end, [best_axis](const SahItem& a, const SahItem& b) { return a.c[best_axis] < b.c[best_axis]; });
+    const size_t me = out.size();
+    out.push_back(DNode<R>{});
+    // the child with the larger surface is walked first: it is the likelier one to shrink the hit distance early
+    Bounds lb = empty_bounds(), rb = empty_bounds();
+    for (size_t i = begin; i < best_split; i++) lb.grow(items[i].b);
+    for (size_t i = best_split; i < end; i++) rb.grow(items[i].b);
+    if (rb.half_area() > lb.half_area()) {
+        std::rotate(items.begin() + begin, items.begin() + best_split, items.begin() + end);
+        best_split = begin + (end - best_split);
+    }
+    Bounds b = emit_sah<R>(s, items, begin, best_split, out, wrap_leaves);
+    b.grow(emit_sah<R>(s, items, best_split, end, out, wrap_leaves));
+    out[me] = box_entry<R>(b, (int32_t)out.size());
+    return b;
+}
+// World-space bounds of `b` under Translate(offset, Rotate(axis, angle, .)): the 8 rotated corners, then the offset.
+Bounds transform_bounds(const mlrt_transform& t, const Bounds& b) {
+    Bounds r = empty_bounds();
+    for (int corner = 0; corner < 8; corner++) {
+        double p[3];
+        for (int k = 0; k < 3; k++) p[k] = (corner >> k) & 1 ? b.hi[k] : b.lo[k];
+        if (t.has_rotate) {  // transforms.rs:116-124 rotate()
+            const int a1 = t.axis, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
+            const double v0 = p[a0], v2 = p[a2];
+            p[a0] = t.cos_theta * v0 + t.sin_theta * v2;
+            p[a2] = -t.sin_theta * v0 + t.cos_theta * v2;
+        }
+        if (t.has_translate) for (int k = 0; k < 3; k++) p[k] += t.offset[k];
+        for (int k = 0; k < 3; k++) { r.lo[k] = std::fmin(r.lo[k], p[k]); r.hi[k] = std::fmax(r.hi[k], p[k]); }
+    }
+    return r;
+}
+void pad_bounds(Bounds& b, double rel) {
+    for (int k = 0; k < 3; k++) { const double pad = rel * (1.0 + std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k]))); b.lo[k] -= pad; b.hi[k] += pad; }
+}
+
 template <typename T>
 int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
     while (blob.size() % 16) blob.push_back(0);
@@ -188,12 +296,66 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
     return off;
 }
 
+// `fast`: SAH device BVHs, bounding-box wrappers around sphere leaves and around the top-level entries whose miss a
+// box can prove (primitives, medium boundaries, whole transform brackets).  None of it changes a closest hit or the
+// conditions under which a medium draws (a ray that misses the boundary's box misses the boundary: volumes.rs:27-34
+// returns None before drawing).  The parity build packs the reference structure verbatim.
 template <typename R>
-Packed<R> pack(const mlrt_scene& s, bool wrap_leaves) {
+Packed<R> pack(const mlrt_scene& s, bool fast, bool sah) {
     Packed<R> P;
     for (int i = 0; i < s.n_objects; i++) {
         const mlrt_object& src = s.objects[i];
         const bool xf = src.transform >= 0 && (s.transforms[src.transform].has_translate || s.transforms[src.transform].has_rotate);
+        // contents in object space, emitted into a scratch list first so a wrapper can be put in front
+        std::vector<DNode<R>> body;
+        Bounds bounds = empty_bounds();
+        bool bounded = false;  // `bounds` encloses everything a ray can interact with inside this object
+        if (src.kind == MLRT_OBJ_BVH) {
+            const int32_t root = s.bvhs[src.bvh].root;
+            if (root == MLRT_BVH_EMPTY) {
+                DNode<R> e{};
+                e.tag = TAG_EMPTY;
+                body.push_back(e);
+            } else if (fast && sah) {
+                std::vector<int32_t> refs;
+                int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
+                collect_leaves(s, root, refs, budget);
+                std::vector<SahItem> items(refs.size());
+                for (size_t k = 0; k < refs.size(); k++) {
+                    items[k].ref = refs[k];
+                    prim_bounds(s, s.prim_refs[refs[k]], items[k].b);
+                    for (int a = 0; a < 3; a++) items[k].c[a] = 0.5 * (items[k].b.lo[a] + items[k].b.hi[a]);
+                }
+                bounds = emit_sah<R>(s, items, 0, items.size(), body, true);
+                bounded = true;
+            } else {
+                int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
+                emit_subtree<R>(s, root, body, budget, fast);
+                if (root >= 0) { for (int k = 0; k < 3; k++) { bounds.lo[k] = s.bvh_nodes[root].bounds_min[k]; bounds.hi[k] = s.bvh_nodes[root].bounds_max[k]; } bounded = true; }
+                else bounded = prim_bounds(s, s.prim_refs[~root], bounds);
+            }
+        } else if (src.kind == MLRT_OBJ_PRIM) {
+            body.push_back(leaf_node<R>(s, src.prim));
+            bounded = prim_bounds(s, src.prim, bounds);
+        } else {  // ConstantMedium: the medium entry, then its boundary primitive
+            DNode<R> e{};
+            e.v[0] = (R)src.neg_inv_density;
+            e.link = src.phase_material;
+            e.tag = TAG_MEDIUM;
+            body.push_back(e);
+            body.push_back(leaf_node<R>(s, src.prim));
+            bounded = prim_bounds(s, src.prim, bounds);
+        }
+        // links inside `body` are relative to its start: rebase them when appending
+        const bool wrap = fast && bounded && !(src.kind == MLRT_OBJ_PRIM && src.prim.kind == MLRT_PRIM_BOX && !xf);
+        const int32_t n_pre = (wrap ? 1 : 0) + (xf ? 1 : 0);
+        const int32_t base = (int32_t)P.nodes.size() + n_pre;
+        const int32_t after = base + (int32_t)body.size() + (xf ? 1 : 0);
+        if (wrap) {
+            Bounds wb = xf ? transform_bounds(s.transforms[src.transform], bounds) : bounds;
+            pad_bounds(wb, 1e-6);
+            P.nodes.push_back(box_entry<R>(wb, after));  // world-space box in front of everything this object emits
+        }
         if (xf) {  // Translate(offset, Rotate(axis, angle, .)) opens: the cursor's ray moves to object space
             const mlrt_transform& t = s.transforms[src.transform];
             DNode<R> e{};
@@ -203,25 +365,9 @@ Packed<R> pack(const mlrt_scene& s, bool wrap_leaves) {
             e.tag = TAG_XFORM | ((t.has_translate ? XF_TRANSLATE : 0) << 4) | ((t.has_rotate ? XF_ROTATE : 0) << 4) | ((t.has_rotate ? t.axis : 0) << 8);
             P.nodes.push_back(e);
         }
-        if (src.kind == MLRT_OBJ_BVH) {
-            const int32_t root = s.bvhs[src.bvh].root;
-            if (root == MLRT_BVH_EMPTY) {
-                DNode<R> e{};
-                e.tag = TAG_EMPTY;
-                P.nodes.push_back(e);
-            } else {
-                int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
-                emit_subtree<R>(s, root, P.nodes, budget, wrap_leaves);
-            }
-        } else if (src.kind == MLRT_OBJ_PRIM) {
-            P.nodes.push_back(leaf_node<R>(s, src.prim));
-        } else {  // ConstantMedium: the medium entry, then its boundary primitive
-            DNode<R> e{};
-            e.v[0] = (R)src.neg_inv_density;
-            e.link = src.phase_material;
-            e.tag = TAG_MEDIUM;
+        for (DNode<R> e : body) {
+            if ((e.tag & TAG_KIND_MASK) == TAG_INNER) e.link += base;
             P.nodes.push_back(e);
-            P.nodes.push_back(leaf_node<R>(s, src.prim));
         }
         if (xf) {
             DNode<R> e{};
@@ -278,6 +424,7 @@ struct mlrt_context {
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
+    unsigned long long* d_stats = nullptr;
     bool lds_scene = false;
     size_t dyn_lds = 0;
     int32_t block_threads = 0, blocks_per_cu = 1, last_grid = 0;
@@ -294,6 +441,7 @@ void destroy(mlrt_context* c) {
     for (unsigned char* p : c->d_image_pixels) (void)hipFree(p);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -326,6 +474,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.n_tiles = K.tiles_per_row * n_rows;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
+    K.stats = c->d_stats;
     K.debug_pixel = -1; K.debug_sample = -1;
     if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }
 }
@@ -413,14 +562,14 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         c->n_cus = prop.multiProcessorCount;
         std::vector<unsigned char> blob;
         if (precision == MLRT_PRECISION_FP32) {
-            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr);
+            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr, std::getenv("MLRT_NO_SAH") == nullptr);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size();
             c->block_threads = mlrt_block_threads_f32();
         } else {
-            Packed<double> P = pack<double>(*scene, false);
+            Packed<double> P = pack<double>(*scene, false, false);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
@@ -444,6 +593,7 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             MLRT_HIP(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DImage), hipMemcpyHostToDevice));
         }
         MLRT_HIP(hipMalloc(&c->d_tile_counter, sizeof(unsigned int)));
+        if (std::getenv("MLRT_STATS")) { MLRT_HIP(hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long))); MLRT_HIP(hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long))); }
         MLRT_HIP(hipEventCreate(&c->ev_start));
         MLRT_HIP(hipEventCreate(&c->ev_stop));
         // LDS plan: the f32 blob is staged in LDS when it fits next to the per-wave accumulators
@@ -525,6 +675,14 @@ int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]) {
     out[1] = ctx->lds_scene ? 1 : 0;
     out[2] = ctx->block_threads;
     out[3] = ctx->last_grid > 0 ? ctx->last_grid : (int64_t)ctx->n_cus * ctx->blocks_per_cu;
+    return MLRT_OK;
+}
+
+// Debug only (MLRT_STATS=1; not part of the ABI headers): copies and clears the in-kernel counters.
+int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[8]) {
+    if (!ctx || !ctx->d_stats) return MLRT_ERR_UNSUPPORTED;
+    if (hipMemcpy(out, ctx->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MLRT_ERR_HIP;
+    (void)hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long));
     return MLRT_OK;
 }
 

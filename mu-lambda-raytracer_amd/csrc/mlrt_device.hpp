@@ -86,6 +86,7 @@ struct KParams {
     int32_t* rgb_out;     // [n_rows][W][3]
     double* accum_out;    // optional [n_rows][W][3]
     unsigned int* tile_counter;
+    unsigned long long* stats;  // optional [8]: iterations, trav lane-steps, special batches, special lanes, shade batches, shade lanes, samples, tiles
     int32_t debug_pixel, debug_sample;  // >= 0: printf the path of that (pixel, sample) from the kernel (MLRT_DEBUG_PIXEL=pixel,sample)
 };
 

@@ -140,8 +140,11 @@ DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
                        uint32_t& o2, uint32_t& o3) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply (v_mad_u64_u32) yields both halves: integer multiplies are quarter rate on CDNA
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -556,8 +559,11 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     const V3 pf = to_v3(p);
     const DMaterial<real> m = S.materials[mat_id];
     const int mk_kind = m.kind & 0xFF;
+    // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
+    // volumes.rs:79): drawn here, before the material branches, so the Philox refill runs for the whole batch at once.
+    V3 s = mk(0, 0, 0);
+    if (mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || mk_kind == MLRT_MAT_ISOTROPIC) s = random_in_unit_sphere(g, key);
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
-        V3 s = random_in_unit_sphere(g, key);
         if (!(dot(normal, s) > (real)0)) s = -s;  // random_in_hemisphere, vec.rs:36-43
         V3 dir = normal + s;
         const real eps = (real)1e-8;
@@ -568,7 +574,7 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     }
     if (mk_kind == MLRT_MAT_METAL) {  // materials.rs:51-61 (quirk Q7)
         const V3 reflected = reflect(unit(dw), normal);
-        const V3 dir = reflected + m.param * random_in_unit_sphere(g, key);
+        const V3 dir = reflected + m.param * s;
         if (dot(dir, normal) > (real)0) {
             thr = thr * ld3(m.albedo);
             o = p; d = to_p3(dir);
@@ -590,7 +596,7 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         return true;
     }
     if (mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
-        const V3 dir = random_in_unit_sphere(g, key);
+        const V3 dir = s;
         thr = thr * texture_value(S, m.tex, u, v, pf);
         o = p; d = to_p3(dir);
         return true;
@@ -703,6 +709,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
 
         const int total = npix * spp;  // the tile's sample queue
         int next = 0;                  // wave-uniform queue head
+        unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0;  // MLRT_STATS (wave-uniform)
         int phase = PH_SHADE;          // every lane starts by asking for a sample
         bool has_path = false;
         int pix = 0, depth = 0;
@@ -732,10 +739,12 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                     phase = PH_SHADE;
                 }
             }
+            if (P.stats) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); }
             const unsigned long long m_trav = __ballot(phase == PH_TRAV);
             // (B) batched special entries
             const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
             if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
+                if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
                 if (phase == PH_SPECIAL) {
                     special_entry(S, c, o, d, g, key);
                     phase = PH_TRAV;
@@ -745,6 +754,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
             const unsigned long long m_shade = __ballot(phase == PH_SHADE);
             const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
             if (batch) {
+                if (P.stats) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
                 const bool mine = phase == PH_SHADE;
                 bool new_ray = false;
                 if (mine && has_path) {
@@ -804,6 +814,12 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                 }
             }
             if (__ballot(phase != PH_IDLE) == 0ull) break;
+        }
+        if (P.stats && lane == 0) {
+            atomicAdd(&P.stats[0], (unsigned long long)st_iter); atomicAdd(&P.stats[1], (unsigned long long)st_steps);
+            atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
+            atomicAdd(&P.stats[4], (unsigned long long)st_hb); atomicAdd(&P.stats[5], (unsigned long long)st_hl);
+            atomicAdd(&P.stats[6], (unsigned long long)total); atomicAdd(&P.stats[7], 1ull);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

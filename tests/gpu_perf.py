@@ -22,6 +22,12 @@ def run(name, W, aspect, spp, reps=3, aperture=0.0, focus=None):
     ms = ms[1:]
     print("%-40s %-12s %4dx%-4d spp %-5d kernel ms min %.1f med %.1f -> %.0f Msamples/s  %s" % (os.path.basename(pkg.LIB_PATH), name, W, H, spp, min(ms), float(np.median(ms)),
           W * H * spp / min(ms) / 1e3, r.info()), flush=True)
+    if os.environ.get('MLRT_STATS'):
+        import ctypes
+        st = (ctypes.c_ulonglong * 8)()
+        if pkg.lib().mlrt_debug_stats(r.ctx, st) == 0:
+            it, steps, sb, sl, hb, hl, samples, tiles = [int(x) for x in st]
+            print('   stats over %d renders: iters/sample %.2f  trav lane-steps/sample %.1f  TRAV util %.3f | special batches: %.2f lanes avg, %.2f specials/sample | shade batches: %.2f lanes avg, %.2f shades/sample' % (reps + 1, it / samples * 64 / 64, steps / samples, steps / (it * 64.0), sl / max(sb, 1), sl / samples, hl / max(hb, 1), hl / samples), flush=True)
     r.close(); w.close()
 
 if __name__ == "__main__":
