@@ -6,10 +6,10 @@ Msamples/s (pixels*spp) for --world=random --seed=42 1200x800 spp=500 (configs[1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full render of the image through the C ABI (mlrt_context_render_device) with the scene already
-resident in HBM.  With N > 1 the image's rows are dealt to the ranks in interleaved 8-row blocks (strong scaling: the
-image is fixed), each rank renders its rows on its own GPU and ONE RCCL gather (torch.distributed, backend nccl)
-collects the 8-bit-valued rows on rank 0 inside the timed region.  PyTorch is plumbing only: device buffers,
-streams, the process group.
+resident in HBM.  With N > 1 the image's rows are dealt to the ranks round-robin (strong scaling: the image is
+fixed), each rank renders its rows on its own GPU and ONE RCCL gather (torch.distributed, backend nccl) collects the
+8-bit-valued rows on rank 0 inside the timed region (mu-lambda-raytracer_amd/rowtile.py).  PyTorch is plumbing only:
+device buffers, streams, the process group.
 """
 import argparse
 import importlib
@@ -28,12 +28,6 @@ WORKLOAD = {"world": "random", "seed": 42, "aspect_ratio": "3:2", "image_width":
 # 85.4 box tests x 32 B + 10.8 sphere tests x 20 B + 2.56 rays x 16 B material + 12 B/pixel output / spp.
 ALGO_BYTES_PER_SAMPLE = 85.4 * 32 + 10.8 * 20 + 2.56 * 16 + 12.0 / 500
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ROW_BLOCK = 8
-
-
-def rows_for_rank(height, rank, world_size, block=ROW_BLOCK):
-    """Interleaved row blocks: block b goes to rank b % world_size (rows differ in cost)."""
-    return [j for j in range(height) if (j // block) % world_size == rank]
 
 
 def cpu_baseline(pkg, cam19, seconds_budget=20.0):
@@ -78,6 +72,7 @@ def main():
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world_size))
     pkg = importlib.import_module("mu-lambda-raytracer_amd")
+    rowtile = importlib.import_module("mu-lambda-raytracer_amd.rowtile")
     if not os.path.exists(pkg.LIB_PATH):
         importlib.import_module("mu-lambda-raytracer_amd.build").build()
     if not torch.cuda.is_available() or pkg.device_count() < 1:
@@ -95,26 +90,16 @@ def main():
     precision = pkg.PRECISION_FP32 if args.precision == "fp32" else pkg.PRECISION_FP64
     renderer = pkg.Renderer(world, cam, params, precision=precision, device=local_rank)
 
-    my_rows = rows_for_rank(H, rank, world_size)
+    my_rows = rowtile.rows_for_rank(H, rank, world_size)
     d_rows = torch.tensor(my_rows, dtype=torch.int32, device=dev)
     d_rgb = torch.zeros((len(my_rows), W, 3), dtype=torch.int32, device=dev)
-    max_rows = max(len(rows_for_rank(H, r, world_size)) for r in range(world_size))
-    send = torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(send) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
-    image = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream(dev)
+    frame = {}
 
     def step():
         renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
-        if world_size > 1:
-            send[: len(my_rows)] = d_rgb.to(torch.uint8)
-            dist.gather(send, gathered, dst=0)  # the one collective of the path: finished rows to rank 0 over xGMI
-            if rank == 0:
-                for r in range(world_size):
-                    rr = rows_for_rank(H, r, world_size)
-                    image[torch.tensor(rr, device=dev)] = gathered[r][: len(rr)]
-        else:
-            image[d_rows.long()] = d_rgb.to(torch.uint8)
+        # the one collective of the path: finished rows to rank 0 over xGMI (a plain scatter into the frame at N = 1)
+        frame["image"] = rowtile.gather_rows(d_rgb.to(torch.uint8), H, rank, world_size)
 
     def barrier():
         if world_size > 1:
@@ -159,11 +144,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
             "config": {"workload": "--world=random --seed=42 --aspect_ratio=3:2 --image_width=1200 --samples_per_pixel=500 (BASELINE.json configs[1])",
-                       "rows_per_rank": len(my_rows), "row_block": ROW_BLOCK, "rng": "philox4x32-10 per (pixel, sample)",
+                       "rows_per_rank": len(my_rows), "row_tiling": "round-robin rows, one gather", "rng": "philox4x32-10 per (pixel, sample)",
                        "kernel_ms_last_launch": kernel_ms, "step_ms_hip_events": step_ms_events, **renderer.info()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
-                         "note": "algorithmic bytes: the scene is LDS/L2 resident, so this is not physical HBM utilisation"},
+                         "note": "algorithmic bytes of the REFERENCE traversal (reference BVH topology, SURVEY.md 8d) per sample x samples/s: "
+                                 "the scene is LDS resident and the device BVH is SAH-built, so this is not physical HBM utilisation and can exceed 1"},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             cam19 = list(cam.origin) + list(cam.lower_left_corner) + list(cam.horizontal) + list(cam.vertical) + list(cam.u) + list(cam.v) + [cam.lens_radius]

@@ -2,6 +2,7 @@
 determinism, row-tiling invariance (the multi-GPU decomposition), the C-ABI host and device entry points agreeing, and
 the full-size image against the reference's README render."""
 import ctypes as C
+import importlib
 import os
 import subprocess
 
@@ -45,11 +46,12 @@ def test_render_is_deterministic(c2):
 
 def test_row_tiling_invariance(c2):
     """Rendering any subset of rows gives exactly the rows of the full image: the property that makes the 1/2/4/8-GPU
-    images bit-identical (rows are dealt to ranks in interleaved blocks, bench.py rows_for_rank)."""
+    images bit-identical (rows are dealt to ranks round-robin, rowtile.rows_for_rank)."""
     mlrt, w, cam, params, r, img = c2
+    rowtile = importlib.import_module("mu-lambda-raytracer_amd.rowtile")
     for world_size in (2, 8):
         for rank in (0, world_size - 1):
-            rows = np.array([j for j in range(800) if (j // 8) % world_size == rank][::5], dtype=np.int32)
+            rows = np.array(rowtile.rows_for_rank(800, rank, world_size)[::5], dtype=np.int32)
             part = r.render(rows)
             assert np.array_equal(part, img[rows])
 
