@@ -253,11 +253,23 @@ Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, 
     std::sort(items.begin() + begin, items.begin() + end, [best_axis](const SahItem& a, const SahItem& b) { return a.c[best_axis] < b.c[best_axis]; });
     const size_t me = out.size();
     out.push_back(DNode<R>{});
-    // the child with the larger surface is walked first: it is the likelier one to shrink the hit distance early
+    // Child order of the threaded walk.  Default: the child with the larger surface first (the likelier one to shrink
+    // the hit distance early).  MLRT_SAH_ORDER=none|eye are experiment hooks (eye: nearer to MLRT_EYE="x,y,z" first).
     Bounds lb = empty_bounds(), rb = empty_bounds();
     for (size_t i = begin; i < best_split; i++) lb.grow(items[i].b);
     for (size_t i = best_split; i < end; i++) rb.grow(items[i].b);
-    if (rb.half_area() > lb.half_area()) {
+    bool swap_children = rb.half_area() > lb.half_area();
+    if (const char* mode = std::getenv("MLRT_SAH_ORDER")) {
+        if (std::strcmp(mode, "none") == 0) swap_children = false;
+        if (std::strcmp(mode, "small") == 0) swap_children = !swap_children;
+        if (std::strcmp(mode, "eye") == 0) {
+            double e[3] = {0, 0, 0};
+            if (const char* eye = std::getenv("MLRT_EYE")) std::sscanf(eye, "%lf,%lf,%lf", &e[0], &e[1], &e[2]);
+            auto dist2 = [&](const Bounds& b) { double d = 0; for (int k = 0; k < 3; k++) { const double c = std::fmax(b.lo[k] - e[k], std::fmax(0.0, e[k] - b.hi[k])); d += c * c; } return d; };
+            swap_children = dist2(rb) < dist2(lb);
+        }
+    }
+    if (swap_children) {
         std::rotate(items.begin() + begin, items.begin() + best_split, items.begin() + end);
         best_split = begin + (end - best_split);
     }

@@ -170,13 +170,30 @@ DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
 DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
 // rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
 DEV real sym(uint32_t w) { return u01(w) * (real)2 + (real)-1; }  // gen_range(-1.0..1.0)
-DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {                // vec.rs:23-30
-    for (;;) {
-        uint32_t w0, w1, w2;
-        rng_next3(g, key, w0, w1, w2);
-        const V3 p = mk(sym(w0), sym(w1), sym(w2));
-        if (length_squared(p) < (real)1) return p;
+// Uniform point in the unit ball.  The reference draws it by rejection (vec.rs:23-30); the device contract (and the
+// oracle's Philox mode, oracle/oracle.cpp closed_form_unit_sphere) draws the same distribution by inverse CDF from
+// exactly three words - z = 2*u1 - 1, phi = 2*pi*u2, r = cbrt((w3>>8 + 1) * 2^-24) - so there is no data-dependent
+// loop: in a 37-lane shading batch the rejection loop ran ~5 times for the unluckiest lane, each time re-running
+// Philox for a handful of lanes.  Fast build: hardware sin/cos (argument in turns), log2/exp2 for the cube root.
+DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {
+    uint32_t w0, w1, w2;
+    rng_next3(g, key, w0, w1, w2);
+    if (kFast) {
+        const float z = (float)sym(w0);
+        const float turn = (float)u01(w1);
+        const float u3 = ((float)(w2 >> 8) + 1.0f) * (float)(1.0 / 16777216.0);
+        const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u3) * (float)(1.0 / 3.0));
+        const float sn = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        const float rs = r * sn;
+        return mk((real)(rs * __builtin_amdgcn_cosf(turn)), (real)(rs * __builtin_amdgcn_sinf(turn)), (real)(r * z));
     }
+    const double z = u01d(w0) * 2.0 + -1.0;
+    const double turn = u01d(w1);
+    const double r = cbrt(((double)(w2 >> 8) + 1.0) * (1.0 / 16777216.0));
+    const double phi = 2.0 * 3.14159265358979323846264338327950288 * turn;
+    const double sn = sqrt(fmax(0.0, 1.0 - z * z));
+    const double rs = r * sn;
+    return mk((real)(rs * cos(phi)), (real)(rs * sin(phi)), (real)(r * z));
 }
 
 // ---------------------------------------------------------------------------------------------- scene view
@@ -613,19 +630,26 @@ DEV V3 background_color(const KParams<real>& P, P3 d) {  // raytrace.rs:29-35, 4
 }
 
 // raytrace.rs:191-193 + Camera::get_ray, camera.rs:40-48, in f64 in both builds: the uniforms are 24-bit values
-// exact in either precision, so the primary ray is bit-identical to the oracle's.  A fresh sample starts at draw 0,
-// hence its first four draws (u, v and the first lens pair) are exactly Philox block 0: no refill branch.
+// exact in either precision, so the primary ray is bit-identical to the oracle's (parity build; the fast build
+// evaluates the lens offset's sin/cos in f32).  A fresh sample's four draws - u, v and the lens sample, drawn by
+// inverse CDF from two words (r = sqrt(u1'), phi = 2*pi*u2; the reference's rejection loop is vec.rs:45-52, quirk Q6:
+// the draws are consumed even when lens_radius == 0) - are exactly Philox block 0: no loop, no refill branch.
 DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
     rng_fill(g, key, 0u);
     g.draw = 4u;
     const double s = ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
     const double t = ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
-    double a = u01d(g.b2) * 2.0 + -1.0, b = u01d(g.b3) * 2.0 + -1.0;
-    while (!(a * a + b * b < 1.0)) {  // random_in_unit_disk, vec.rs:45-52 (quirk Q6: drawn even when lens_radius == 0)
-        a = u01d(rng_next(g, key)) * 2.0 + -1.0;
-        b = u01d(rng_next(g, key)) * 2.0 + -1.0;
+    double rdx = 0.0, rdy = 0.0;
+    if (P.lens_radius != 0.0) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
+        const double u1 = ((double)(g.b2 >> 8) + 1.0) * (1.0 / 16777216.0);
+        const double turn = u01d(g.b3);
+        double cs, sn;
+        if (kFast) { cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
+        else { const double phi = 2.0 * 3.14159265358979323846264338327950288 * turn; cs = cos(phi); sn = sin(phi); }
+        const double r = sqrt(u1);
+        rdx = P.lens_radius * (r * cs);
+        rdy = P.lens_radius * (r * sn);
     }
-    const double rdx = P.lens_radius * a, rdy = P.lens_radius * b;
     const P3 offset = ld3p(P.cam_u) * rdx + ld3p(P.cam_v) * rdy;
     const P3 origin = ld3p(P.cam_origin);
     o = origin + offset;

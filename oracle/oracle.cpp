@@ -10,6 +10,24 @@ namespace orc {
 
 thread_local Stats g_stats;
 
+// Inverse-CDF samplers of the device contract (see oracle_core.hpp).  Draw order: u1, u2, u3 / u1, u2.
+Vec3 closed_form_unit_sphere(Rng& rng) {
+    PhiloxStream& ps = static_cast<PhiloxStream&>(rng);
+    const double z = ps.uniform01() * 2.0 + -1.0;
+    const double turn = ps.uniform01();
+    const double r = std::cbrt(ps.uniform_0_1_closed_top());
+    const double phi = 2.0 * PI * turn;
+    const double s = std::sqrt(std::fmax(0.0, 1.0 - z * z));
+    const double rs = r * s;
+    return Vec3(rs * std::cos(phi), rs * std::sin(phi), r * z);
+}
+Vec3 closed_form_unit_disk(Rng& rng) {
+    PhiloxStream& ps = static_cast<PhiloxStream&>(rng);
+    const double r = std::sqrt(ps.uniform_0_1_closed_top());
+    const double phi = 2.0 * PI * ps.uniform01();
+    return Vec3(r * std::cos(phi), r * std::sin(phi), 0.0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // worlds.rs
 // ------------------------------------------------------------------------------------------------
@@ -361,6 +379,16 @@ void orc_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t ou
 void orc_philox_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, int n, double* out) {
     PhiloxStream s(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = s.uniform01();
+}
+
+// n samples of the unit-ball / unit-disk samplers: mode 0 = reference rejection on Pcg64(seed), 1 = device contract on Philox(seed, pixel 0, sample i)
+void orc_sample_ball(uint64_t seed, int mode, int n, double* out) {
+    if (mode == 0) { Pcg64 g = Pcg64::seed_from_u64(seed); for (int i = 0; i < n; i++) { Vec3 p = random_in_unit_sphere(g); out[3 * i] = p.e[0]; out[3 * i + 1] = p.e[1]; out[3 * i + 2] = p.e[2]; } }
+    else for (int i = 0; i < n; i++) { PhiloxStream g(seed, 0, (uint32_t)i); Vec3 p = random_in_unit_sphere(g); out[3 * i] = p.e[0]; out[3 * i + 1] = p.e[1]; out[3 * i + 2] = p.e[2]; }
+}
+void orc_sample_disk(uint64_t seed, int mode, int n, double* out) {
+    if (mode == 0) { Pcg64 g = Pcg64::seed_from_u64(seed); for (int i = 0; i < n; i++) { Vec3 p = random_in_unit_disk(g); out[2 * i] = p.e[0]; out[2 * i + 1] = p.e[1]; } }
+    else for (int i = 0; i < n; i++) { PhiloxStream g(seed, 0, (uint32_t)i); Vec3 p = random_in_unit_disk(g); out[2 * i] = p.e[0]; out[2 * i + 1] = p.e[1]; }
 }
 
 int orc_aabb_hit(const double mn[3], const double mx[3], const double o[3], const double d[3], double tmin, double tmax) {

@@ -101,9 +101,13 @@ struct Ray {  // vec.rs:215-228
 //    The HIP kernel consumes the identical words in the identical order, which makes
 //    oracle[Philox] vs GPU[Philox] comparable sample for sample.
 // ------------------------------------------------------------------------------------------------
+struct Vec3;
 struct Rng {
     virtual ~Rng() {}
     virtual uint64_t next_u64() = 0;
+    // vec.rs:23-30 / :45-52.  The reference (and the Pcg64 mode here) draws these by rejection; the device contract
+    // (PhiloxStream) draws the SAME distributions by inverse CDF from exactly 3 / 2 uniforms, see below.
+    virtual bool closed_form_samplers() const { return false; }
     // uniform in [0,1): the value rand 0.8.3's UniformFloat::sample_single forms before scaling.
     virtual double uniform01() = 0;
     // rand 0.8.3 UniformFloat<f64>::sample_single: value0_1 * (high-low) + low, retried if >= high.
@@ -204,6 +208,13 @@ struct PhiloxStream : Rng {
         return buf[(draw++) & 3];
     }
     uint64_t next_u64() override { std::fprintf(stderr, "oracle: PhiloxStream::next_u64 is not part of the render path\n"); std::abort(); }
+    bool closed_form_samplers() const override { return true; }
+    // the radius draw maps word w to (w>>8 + 1) * 2^-24 in (0, 1]: r = cbrt(.) is never 0 (a zero vector would make an
+    // Isotropic scatter direction degenerate with probability 2^-24 instead of the rejection loop's ~2^-72)
+    double uniform_0_1_closed_top() {
+        g_stats.draws++;
+        return ((double)(next_u32() >> 8) + 1.0) * (1.0 / 16777216.0);
+    }
     double uniform01() override {
         g_stats.draws++;
         return (double)(next_u32() >> 8) * (1.0 / 16777216.0);
@@ -217,7 +228,14 @@ inline Vec3 vec3_random(double lo, double hi, Rng& rng) {  // vec.rs:15-17
     double c = rng.gen_range(lo, hi);
     return Vec3(a, b, c);
 }
+// Device contract (Philox mode): uniform point in the unit ball by inverse CDF from exactly three draws -
+// z = 2*u1 - 1, phi = 2*pi*u2, r = cbrt(u3') - the same distribution as the reference's rejection loop, which stays
+// in force for the Pcg64 mode (tests/test_oracle_samplers.py checks the two statistically and at image level).
+struct PhiloxStream;
+Vec3 closed_form_unit_sphere(Rng& rng);
+Vec3 closed_form_unit_disk(Rng& rng);
 inline Vec3 random_in_unit_sphere(Rng& rng) {  // vec.rs:23-30
+    if (rng.closed_form_samplers()) return closed_form_unit_sphere(rng);
     for (;;) {
         Vec3 p = vec3_random(-1.0, 1.0, rng);
         if (p.length_squared() < 1.0) return p;
@@ -229,6 +247,7 @@ inline Vec3 random_in_hemisphere(const Vec3& normal, Rng& rng) {  // vec.rs:36-4
     return -s;
 }
 inline Vec3 random_in_unit_disk(Rng& rng) {  // vec.rs:45-52
+    if (rng.closed_form_samplers()) return closed_form_unit_disk(rng);
     for (;;) {
         double a = rng.gen_range(-1.0, 1.0);
         double b = rng.gen_range(-1.0, 1.0);
