@@ -669,10 +669,10 @@ DEV unsigned long long to_fixed(real c) {
 #define MLRT_BOX_SPECIAL 0
 #endif
 #ifndef MLRT_T_SPECIAL
-#define MLRT_T_SPECIAL 24
+#define MLRT_T_SPECIAL 32
 #endif
 #ifndef MLRT_T_SHADE
-#define MLRT_T_SHADE 24
+#define MLRT_T_SHADE 32
 #endif
 enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3 };
 
