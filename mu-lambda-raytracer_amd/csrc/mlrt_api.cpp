@@ -437,6 +437,8 @@ struct mlrt_context {
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
     unsigned long long* d_stats = nullptr;
+    unsigned long long* d_acc = nullptr;  // frame accumulation buffer, grown on demand
+    size_t acc_elems = 0;
     bool lds_scene = false;
     size_t dyn_lds = 0;
     int32_t block_threads = 0, blocks_per_cu = 1, last_grid = 0;
@@ -454,6 +456,7 @@ void destroy(mlrt_context* c) {
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -478,12 +481,30 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
-    int pix = 1;
-    while (pix < 64 && (int64_t)pix * p->samples_per_pixel < 4096) pix *= 2;
-    while (pix > 1 && pix > p->image_width) pix /= 2;
+    // Tile geometry: ~MLRT_TILE_SAMPLES samples per tile (default 1024): enough to keep 64 lanes busy through the tile's
+    // ramp-up and drain, small enough that heavy-tailed tile costs (final_scene: 50-bounce paths; C2: sky vs spheres)
+    // average out over many tiles per wave - with 8000-sample tiles the waves were alive only 75 % of the kernel's
+    // duration (rocprof: sum of wave lifetimes vs wall), with 1000-sample tiles 99 %.  Low spp: several pixels per tile;
+    // high spp: a pixel's samples are split into chunks (the integer accumulation makes the split invisible).
+    int target = 1024;
+    if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
+    int pix = 1, spt = p->samples_per_pixel, chunks = 1;
+    if (p->samples_per_pixel >= target) {
+        chunks = (p->samples_per_pixel + target - 1) / target;
+        spt = (p->samples_per_pixel + chunks - 1) / chunks;
+        chunks = (p->samples_per_pixel + spt - 1) / spt;
+    } else {
+        pix = std::min(64, std::max(1, (target + p->samples_per_pixel / 2) / p->samples_per_pixel));  // nearest whole number of pixels
+        pix = std::min(pix, (int)p->image_width);
+    }
     K.pix_per_tile = pix;
     K.tiles_per_row = (p->image_width + pix - 1) / pix;
-    K.n_tiles = K.tiles_per_row * n_rows;
+    K.spp_per_tile = spt;
+    K.chunks = chunks;
+    const int64_t n_tiles64 = (int64_t)K.tiles_per_row * n_rows * chunks;
+    MLRT_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
+    K.n_tiles = (int32_t)n_tiles64;
+    K.acc_global = c->d_acc;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
     K.stats = c->d_stats;
@@ -505,6 +526,16 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
             hipStream_t stream) {
     if (n_rows == 0) return;
     MLRT_HIP(hipSetDevice(c->device));
+    const size_t need = (size_t)n_rows * (size_t)p->image_width * 3;
+    if (need > c->acc_elems) {
+        // grows only when a larger frame is requested (not in the steady state of a render loop)
+        MLRT_HIP(hipStreamSynchronize(stream));
+        if (c->d_acc) MLRT_HIP(hipFree(c->d_acc));
+        c->d_acc = nullptr; c->acc_elems = 0;
+        MLRT_HIP(hipMalloc(&c->d_acc, need * sizeof(unsigned long long)));
+        c->acc_elems = need;
+    }
+    MLRT_HIP(hipMemsetAsync(c->d_acc, 0, need * sizeof(unsigned long long), stream));
     MLRT_HIP(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), stream));
     const int waves_per_block = c->block_threads / 64;
     int rc;

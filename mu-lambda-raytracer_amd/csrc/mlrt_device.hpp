@@ -80,10 +80,11 @@ struct KParams {
     uint32_t seed_lo, seed_hi;
     int32_t bg_kind;
     R bg_top[3], bg_bottom[3];
-    // work decomposition: a tile = pix_per_tile consecutive pixels of one row
+    // work decomposition: a tile = pix_per_tile consecutive pixels of one row x one chunk of spp_per_tile samples
     const int32_t* rows;  // device array of row indices or nullptr (= identity)
-    int32_t n_rows, pix_per_tile, tiles_per_row, n_tiles;
-    int32_t* rgb_out;     // [n_rows][W][3]
+    int32_t n_rows, pix_per_tile, tiles_per_row, spp_per_tile, chunks, n_tiles;
+    unsigned long long* acc_global;  // [n_rows][W][3] 2^-32 fixed-point colour sums (integer adds: order independent)
+    int32_t* rgb_out;     // [n_rows][W][3], written by the resolve kernel
     double* accum_out;    // optional [n_rows][W][3]
     unsigned int* tile_counter;
     unsigned long long* stats;  // optional [8]: iterations, trav lane-steps, special batches, special lanes, shade batches, shade lanes, samples, tiles

@@ -656,7 +656,7 @@ DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j
     d = ld3p(P.cam_llc) + s * ld3p(P.cam_horizontal) + t * ld3p(P.cam_vertical) - origin - offset;
 }
 
-// 2^-32 fixed point; integer accumulation is order independent.  NaN/negative radiance cannot occur on this
+// 2^-32 fixed point; integer accumulation is order independent (within a tile in LDS, across tiles in HBM).  NaN/negative radiance cannot occur on this
 // path (near_zero guard, abs() under the refraction root); they are clamped to 0 rather than poisoning the sum.
 DEV unsigned long long to_fixed(real c) {
     double x = (double)c;
@@ -723,15 +723,20 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
         if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= P.n_tiles) break;
-        const int row_k = tile / P.tiles_per_row;
-        const int x0 = (tile - row_k * P.tiles_per_row) * P.pix_per_tile;
+        // tile -> (row, pixel group, sample chunk); chunks of one pixel group are adjacent in the queue
+        const int group = tile / P.chunks;
+        const int chunk = tile - group * P.chunks;
+        const int row_k = group / P.tiles_per_row;
+        const int x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
         const int npix = min(P.pix_per_tile, P.width - x0);
+        const int s0 = chunk * P.spp_per_tile;
+        const int ns = min(P.spp_per_tile, spp - s0);  // samples of every pixel handled by this tile
         const int j = P.rows ? P.rows[row_k] : row_k;
         for (int i = lane; i < npix * 3; i += 64) acc[i] = 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        const int total = npix * spp;  // the tile's sample queue
+        const int total = npix * ns;  // the tile's sample queue
         int next = 0;                  // wave-uniform queue head
         unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0;  // MLRT_STATS (wave-uniform)
         int phase = PH_SHADE;          // every lane starts by asking for a sample
@@ -813,8 +818,8 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
                     const int q = next + rank;
                     if (want && q < total) {
-                        pix = q / spp;
-                        const int s = q - pix * spp;
+                        pix = q / ns;
+                        const int s = s0 + (q - pix * ns);
                         g.pixel = (uint32_t)(j * P.width + x0 + pix);
                         g.sample = (uint32_t)s;
                         gen_camera_ray(P, g, key, x0 + pix, j, o, d);
@@ -847,18 +852,27 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // fused epilogue: to_rgb (raytrace.rs:59-68) in f64 for every pixel of the tile
+        // flush the tile's sums into the frame's accumulation buffer: integer atomics, so the frame is bit-identical
+        // however the pixels' samples were split into tiles and whichever wave / GPU rendered them
         for (int i = lane; i < npix * 3; i += 64) {
-            const double sum = (double)acc[i] * (1.0 / 4294967296.0);
             const size_t out = ((size_t)row_k * P.width + x0) * 3 + i;
-            if (P.accum_out) P.accum_out[out] = sum;
-            const double scale = 1.0 / (double)spp;
-            double cc = sqrt(sum * scale);
-            cc = cc < 0.0 ? 0.0 : (cc > 0.99999999 ? 0.99999999 : cc);
-            P.rgb_out[out] = (int32_t)(255.999 * cc);
+            atomicAdd(&P.acc_global[out], acc[i]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// to_rgb (raytrace.rs:59-68) in f64 over the finished accumulation buffer.
+__global__ void mlrt_resolve_kernel(const unsigned long long* acc, int n, int spp, int32_t* rgb_out, double* accum_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double sum = (double)acc[i] * (1.0 / 4294967296.0);
+        if (accum_out) accum_out[i] = sum;
+        const double scale = 1.0 / (double)spp;
+        double cc = sqrt(sum * scale);
+        cc = cc < 0.0 ? 0.0 : (cc > 0.99999999 ? 0.99999999 : cc);
+        rgb_out[i] = (int32_t)(255.999 * cc);
     }
 }
 
@@ -875,6 +889,11 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int lds_
         hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<true>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
     } else {
         hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<false>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
+    }
+    {
+        const int n = P.n_rows * P.width * 3;
+        const int rgrid = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+        hipLaunchKernelGGL(MLRT_NS::mlrt_resolve_kernel, dim3((unsigned)rgrid), dim3(256), 0, stream, P.acc_global, n, P.spp, P.rgb_out, P.accum_out);
     }
     return (int)hipGetLastError();
 }
