@@ -481,12 +481,12 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
-    // Tile geometry: ~MLRT_TILE_SAMPLES samples per tile (default 1024): enough to keep 64 lanes busy through the tile's
+    // Tile geometry: ~MLRT_TILE_SAMPLES samples per tile (default 512): enough to keep 64 lanes busy through the tile's
     // ramp-up and drain, small enough that heavy-tailed tile costs (final_scene: 50-bounce paths; C2: sky vs spheres)
     // average out over many tiles per wave - with 8000-sample tiles the waves were alive only 75 % of the kernel's
     // duration (rocprof: sum of wave lifetimes vs wall), with 1000-sample tiles 99 %.  Low spp: several pixels per tile;
     // high spp: a pixel's samples are split into chunks (the integer accumulation makes the split invisible).
-    int target = 1024;
+    int target = 512;
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
     int pix = 1, spt = p->samples_per_pixel, chunks = 1;
     if (p->samples_per_pixel >= target) {
@@ -494,7 +494,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
         spt = (p->samples_per_pixel + chunks - 1) / chunks;
         chunks = (p->samples_per_pixel + spt - 1) / spt;
     } else {
-        pix = std::min(64, std::max(1, (target + p->samples_per_pixel / 2) / p->samples_per_pixel));  // nearest whole number of pixels
+        pix = std::min(4, std::max(1, (target + p->samples_per_pixel / 2) / p->samples_per_pixel));  // nearest whole number of pixels (kMaxPixPerTile)
         pix = std::min(pix, (int)p->image_width);
     }
     K.pix_per_tile = pix;

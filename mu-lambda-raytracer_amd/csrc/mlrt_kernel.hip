@@ -53,8 +53,12 @@ using namespace mlrt;
 
 typedef MLRT_REAL real;
 constexpr bool kFast = sizeof(real) == 4;
-constexpr int kMaxPixPerTile = 64;
-constexpr int kAccBytesPerWave = kMaxPixPerTile * 3 * 8;
+constexpr int kMaxPixPerTile = 4;
+// per wave: a ring of kBanks accumulator banks (tiles in flight: the one being handed out and older ones whose last
+// paths are still running) + remaining / out_base / n_values per bank
+constexpr int kBanks = 8;
+constexpr int kBankValues = kMaxPixPerTile * 3;
+constexpr int kAccBytesPerWave = kBanks * kBankValues * 8 + kBanks * 12;
 
 // ---------------------------------------------------------------------------------------------- math helpers
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -674,7 +678,7 @@ DEV unsigned long long to_fixed(real c) {
 #ifndef MLRT_T_SHADE
 #define MLRT_T_SHADE 32
 #endif
-enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3 };
+enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  // WAIT: no sample to be had until a bank of the ring drains
 
 // The megakernel.  Every lane runs a small state machine over its current path:
 //   PH_TRAV    one cheap step per loop iteration: fetch an entry, slab-test it, follow the skip link
@@ -712,157 +716,197 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
     S.perlin_perm = reinterpret_cast<const uint16_t*>(base + P.off_perlin_perm);
     S.images = P.images;
 
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_base + wave * kAccBytesPerWave);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_base + wave * kAccBytesPerWave);  // [kBanks][kBankValues]
+    int* bank_remaining = reinterpret_cast<int*>(acc + kBanks * kBankValues);  // samples of the bank's tile not yet finished
+    int* bank_out = bank_remaining + kBanks;                                    // first index into acc_global
+    int* bank_values = bank_remaining + 2 * kBanks;                             // npix * 3
     const RngKey key = {P.seed_lo, P.seed_hi};
     const int spp = P.spp;
     const int n_nodes = P.n_nodes;
 
+    if (lane < kBanks) bank_remaining[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // The wave's stream of tiles.  A tile = pix_per_tile consecutive pixels of a row x one chunk of samples, pulled from
+    // the global queue; its pixels*samples form a queue handed out to lanes in order.  Tiles OVERLAP: when the current
+    // tile's queue is exhausted the next one is opened at once (into the next accumulator bank of the ring) while the
+    // last paths of older tiles are still running, so there is no per-tile drain.  All of this state is wave-uniform.
+    int t_bank = kBanks - 1, t_total = 0, t_next = 0, t_ns = 1, t_s0 = 0, t_x0 = 0, t_j = 0;
+    bool queue_done = false;
+    unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
+
+    int phase = PH_SHADE;  // every lane starts by asking for a sample
+    bool has_path = false;
+    int pix = 0, depth = 0;  // pix: value index base of the lane's pixel inside its bank (bank * kBankValues + pixel * 3)
+    P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
+    V3 thr = mk(1, 1, 1);
+    Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    Cursor c;
+    c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+    c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
+
     for (;;) {
-        // one tile per wave at a time, pulled from the global queue
-        int tile = 0;
-        if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= P.n_tiles) break;
-        // tile -> (row, pixel group, sample chunk); chunks of one pixel group are adjacent in the queue
-        const int group = tile / P.chunks;
-        const int chunk = tile - group * P.chunks;
-        const int row_k = group / P.tiles_per_row;
-        const int x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
-        const int npix = min(P.pix_per_tile, P.width - x0);
-        const int s0 = chunk * P.spp_per_tile;
-        const int ns = min(P.spp_per_tile, spp - s0);  // samples of every pixel handled by this tile
-        const int j = P.rows ? P.rows[row_k] : row_k;
-        for (int i = lane; i < npix * 3; i += 64) acc[i] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const int total = npix * ns;  // the tile's sample queue
-        int next = 0;                  // wave-uniform queue head
-        unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0;  // MLRT_STATS (wave-uniform)
-        int phase = PH_SHADE;          // every lane starts by asking for a sample
-        bool has_path = false;
-        int pix = 0, depth = 0;
-        P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
-        V3 thr = mk(1, 1, 1);
-        Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        Cursor c;
-        c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
-        c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
-
-        for (;;) {
-            // (A) one traversal step
-            if (phase == PH_TRAV) {
-                if (c.node < n_nodes) {
-                    const DNode<real> n = S.nodes[c.node];
-                    const int kind = n.tag & TAG_KIND_MASK;
-                    if (kind == TAG_INNER) {
-                        c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
-                    } else if (kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
-                        double t; int aux = 0;
-                        if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
-                        c.node += 1;
+        // (A) one traversal step
+        if (phase == PH_TRAV) {
+            if (c.node < n_nodes) {
+                const DNode<real> n = S.nodes[c.node];
+                const int kind = n.tag & TAG_KIND_MASK;
+                if (kind == TAG_INNER) {
+                    c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
+                } else if (kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
+                    double t; int aux = 0;
+                    if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+                    c.node += 1;
+                } else {
+                    phase = PH_SPECIAL;
+                }
+            } else {
+                phase = PH_SHADE;
+            }
+        }
+        if (P.stats) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); }
+        const unsigned long long m_trav = __ballot(phase == PH_TRAV);
+        // (B) batched special entries
+        const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
+        if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
+            if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
+            if (phase == PH_SPECIAL) {
+                special_entry(S, c, o, d, g, key);
+                phase = PH_TRAV;
+            }
+        }
+        // (C) batched shading, path termination and regeneration
+        const unsigned long long m_shade = __ballot(phase == PH_SHADE);
+        const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
+        if (batch) {
+            if (P.stats) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
+            const bool mine = phase == PH_SHADE;
+            bool new_ray = false;
+            bool freed = false;  // this lane flushed a bank: starved lanes may try again
+            if (mine && has_path) {
+                if (P.debug_pixel >= 0 && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
+                    printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
+                           c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
+                V3 radiance = mk(0, 0, 0);
+                bool done = true;
+                if (c.hit_node >= 0) {
+                    V3 emitted = mk(0, 0, 0);
+                    if (shade(S, c, o, d, thr, emitted, g, key)) {
+                        depth--;
+                        if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
                     } else {
-                        phase = PH_SPECIAL;
+                        radiance = thr * emitted;
                     }
                 } else {
-                    phase = PH_SHADE;
+                    radiance = thr * background_color(P, d);
                 }
-            }
-            if (P.stats) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); }
-            const unsigned long long m_trav = __ballot(phase == PH_TRAV);
-            // (B) batched special entries
-            const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
-            if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
-                if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
-                if (phase == PH_SPECIAL) {
-                    special_entry(S, c, o, d, g, key);
-                    phase = PH_TRAV;
-                }
-            }
-            // (C) batched shading, path termination and regeneration
-            const unsigned long long m_shade = __ballot(phase == PH_SHADE);
-            const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
-            if (batch) {
-                if (P.stats) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
-                const bool mine = phase == PH_SHADE;
-                bool new_ray = false;
-                if (mine && has_path) {
-                    V3 radiance = mk(0, 0, 0);
-                    bool done = true;
-                    if (P.debug_pixel >= 0 && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
-                        printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
-                               c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
-                    if (c.hit_node >= 0) {
-                        V3 emitted = mk(0, 0, 0);
-                        if (shade(S, c, o, d, thr, emitted, g, key)) {
-                            depth--;
-                            if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
-                        } else {
-                            radiance = thr * emitted;
-                        }
-                    } else {
-                        radiance = thr * background_color(P, d);
-                    }
-                    if (done) {
-                        atomicAdd(&acc[pix * 3 + 0], to_fixed(radiance.x));
-                        atomicAdd(&acc[pix * 3 + 1], to_fixed(radiance.y));
-                        atomicAdd(&acc[pix * 3 + 2], to_fixed(radiance.z));
-                        has_path = false;
+                if (done) {
+                    atomicAdd(&acc[pix + 0], to_fixed(radiance.x));
+                    atomicAdd(&acc[pix + 1], to_fixed(radiance.y));
+                    atomicAdd(&acc[pix + 2], to_fixed(radiance.z));
+                    has_path = false;
+                    // the lane that finishes the last sample of a tile flushes that tile's sums into the frame buffer:
+                    // integer atomics, so the frame is bit-identical however pixels' samples were split into tiles and
+                    // whichever wave / GPU rendered them (LDS operations of a wave execute in order, so every add of
+                    // the tile is visible to the lane that sees the count reach zero)
+                    const int bank = pix / kBankValues;
+                    if (atomicSub(&bank_remaining[bank], 1) == 1) {
+                        const int n_values = bank_values[bank];
+                        const int out0 = bank_out[bank];
+                        for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * kBankValues + i]);
+                        freed = true;
                     }
                 }
-                // Path regeneration, in wave-uniform control flow so that the queue head `next` stays uniform: the
-                // batch's lanes without a path take the next queue entries in lane order.
-                const bool want = mine && !has_path;
+            }
+            if (__ballot(freed) != 0ull && phase == PH_WAIT) phase = PH_SHADE;  // they join the next shading batch
+            // Path regeneration, in wave-uniform control flow so the tile state stays uniform: the batch's lanes without
+            // a path take the next queue entries in lane order, opening the next tile when the current one runs out.
+            bool want = mine && !has_path;
+            for (;;) {
                 const unsigned long long need = __ballot(want);
-                if (need != 0ull && next < total) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
-                    const int q = next + rank;
-                    if (want && q < total) {
-                        pix = q / ns;
-                        const int s = s0 + (q - pix * ns);
-                        g.pixel = (uint32_t)(j * P.width + x0 + pix);
-                        g.sample = (uint32_t)s;
-                        gen_camera_ray(P, g, key, x0 + pix, j, o, d);
-                        thr = mk(1, 1, 1);
-                        depth = P.max_depth;
-                        has_path = depth > 0;  // max_depth == 0: the sample contributes 0 (raytrace.rs:87-89)
-                        new_ray = has_path;
+                if (need == 0ull) break;
+                if (t_next >= t_total) {
+                    // open the next tile into the next bank of the ring, if that bank's previous tile has fully drained
+                    const int nb = (t_bank + 1) % kBanks;
+                    // (LDS / global loads below are wave-uniform by construction; readfirstlane tells the compiler, which
+                    // keeps the tile state in scalar registers)
+                    if (queue_done || __builtin_amdgcn_readfirstlane(bank_remaining[nb]) != 0) break;
+                    int tile = 0;
+                    if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
+                    tile = __builtin_amdgcn_readfirstlane(tile);
+                    if (tile >= P.n_tiles) { queue_done = true; break; }
+                    // tile -> (row, pixel group, sample chunk); chunks of one pixel group are adjacent in the queue
+                    const int group = tile / P.chunks;
+                    const int chunk = tile - group * P.chunks;
+                    const int row_k = group / P.tiles_per_row;
+                    t_x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
+                    const int npix = min(P.pix_per_tile, P.width - t_x0);
+                    t_s0 = chunk * P.spp_per_tile;
+                    t_ns = min(P.spp_per_tile, spp - t_s0);  // samples of every pixel handled by this tile
+                    t_j = P.rows ? __builtin_amdgcn_readfirstlane(P.rows[row_k]) : row_k;
+                    t_total = npix * t_ns;
+                    t_next = 0;
+                    t_bank = nb;
+                    if (lane < npix * 3) acc[nb * kBankValues + lane] = 0ull;
+                    if (lane == 0) {
+                        bank_remaining[nb] = t_total;
+                        bank_out[nb] = (row_k * P.width + t_x0) * 3;
+                        bank_values[nb] = npix * 3;
                     }
-                    next = min(total, next + (int)__popcll(need));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (P.stats) { st_tiles++; st_samples += (unsigned int)t_total; }
                 }
-                if (mine) {
-                    if (new_ray) {
-                        c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
-                        Ray wr;
-                        wr.o = o; wr.d = d;
-                        c.sr = slab_ray(wr);
-                        phase = PH_TRAV;
-                    } else if (!has_path) {
-                        phase = next < total ? PH_SHADE : PH_IDLE;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
+                const int avail = t_total - t_next;
+                if (want && rank < avail) {
+                    const int q = t_next + rank;
+                    const int p_in_tile = q / t_ns;
+                    const int smp = t_s0 + (q - p_in_tile * t_ns);
+                    pix = t_bank * kBankValues + p_in_tile * 3;
+                    g.pixel = (uint32_t)(t_j * P.width + t_x0 + p_in_tile);
+                    g.sample = (uint32_t)smp;
+                    gen_camera_ray(P, g, key, t_x0 + p_in_tile, t_j, o, d);
+                    thr = mk(1, 1, 1);
+                    depth = P.max_depth;
+                    has_path = true;
+                    new_ray = depth > 0;
+                    want = false;
+                    if (!new_ray) {  // max_depth == 0: the sample contributes 0 (raytrace.rs:87-89)
+                        has_path = false;
+                        const int bank = t_bank;
+                        if (atomicSub(&bank_remaining[bank], 1) == 1) {
+                            const int n_values = bank_values[bank];
+                            const int out0 = bank_out[bank];
+                            for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * kBankValues + i]);
+                        }
                     }
+                }
+                t_next += min((int)__popcll(need), avail);
+            }
+            if (mine) {
+                if (new_ray) {
+                    c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+                    Ray wr;
+                    wr.o = o; wr.d = d;
+                    c.sr = slab_ray(wr);
+                    phase = PH_TRAV;
+                } else if (!has_path) {
+                    // no sample to be had right now: the stream is finished, or the ring is full (woken when a bank drains)
+                    phase = (queue_done && t_next >= t_total) ? PH_IDLE : PH_WAIT;
                 }
             }
-            if (__ballot(phase != PH_IDLE) == 0ull) break;
         }
-        if (P.stats && lane == 0) {
-            atomicAdd(&P.stats[0], (unsigned long long)st_iter); atomicAdd(&P.stats[1], (unsigned long long)st_steps);
-            atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
-            atomicAdd(&P.stats[4], (unsigned long long)st_hb); atomicAdd(&P.stats[5], (unsigned long long)st_hl);
-            atomicAdd(&P.stats[6], (unsigned long long)total); atomicAdd(&P.stats[7], 1ull);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // flush the tile's sums into the frame's accumulation buffer: integer atomics, so the frame is bit-identical
-        // however the pixels' samples were split into tiles and whichever wave / GPU rendered them
-        for (int i = lane; i < npix * 3; i += 64) {
-            const size_t out = ((size_t)row_k * P.width + x0) * 3 + i;
-            atomicAdd(&P.acc_global[out], acc[i]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (__ballot(phase != PH_IDLE) == 0ull) break;
+    }
+    if (P.stats && lane == 0) {
+        atomicAdd(&P.stats[0], (unsigned long long)st_iter); atomicAdd(&P.stats[1], (unsigned long long)st_steps);
+        atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
+        atomicAdd(&P.stats[4], (unsigned long long)st_hb); atomicAdd(&P.stats[5], (unsigned long long)st_hl);
+        atomicAdd(&P.stats[6], (unsigned long long)st_samples); atomicAdd(&P.stats[7], (unsigned long long)st_tiles);
     }
 }
-
 
 // to_rgb (raytrace.rs:59-68) in f64 over the finished accumulation buffer.
 __global__ void mlrt_resolve_kernel(const unsigned long long* acc, int n, int spp, int32_t* rgb_out, double* accum_out) {
