@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo (rows gathered through host memory) only to rehearse N>1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import numpy as np
@@ -77,18 +79,25 @@ def main():
         importlib.import_module("mu-lambda-raytracer_amd.build").build()
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs are visible (one rank per GPU)" % (local_rank, n_dev))
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
 
     W, H, spp = WORKLOAD["image_width"], WORKLOAD["image_height"], WORKLOAD["samples_per_pixel"]
     world = pkg.World(WORKLOAD["world"], WORKLOAD["seed"])
     cam = pkg.default_camera(world, 1.5)
     params = pkg.make_params(world, W, H, spp, WORKLOAD["max_depth"])
     precision = pkg.PRECISION_FP32 if args.precision == "fp32" else pkg.PRECISION_FP64
-    renderer = pkg.Renderer(world, cam, params, precision=precision, device=local_rank)
+    renderer = pkg.Renderer(world, cam, params, precision=precision, device=device_index)
 
     my_rows = rowtile.rows_for_rank(H, rank, world_size)
     d_rows = torch.tensor(my_rows, dtype=torch.int32, device=dev)
@@ -99,7 +108,10 @@ def main():
     def step():
         renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
         # the one collective of the path: finished rows to rank 0 over xGMI (a plain scatter into the frame at N = 1)
-        frame["image"] = rowtile.gather_rows(d_rgb.to(torch.uint8), H, rank, world_size)
+        rows_u8 = d_rgb.to(torch.uint8)
+        if args.backend == "gloo" and world_size > 1:
+            rows_u8 = rows_u8.cpu()  # rehearsal only
+        frame["image"] = rowtile.gather_rows(rows_u8, H, rank, world_size)
 
     def barrier():
         if world_size > 1:
