@@ -59,3 +59,10 @@ def test_no_cpu_fallback_without_a_device(mlrt):
         mlrt.Renderer(w, cam, p)
     assert e.value.code == mlrt.MLRT_ERR_NO_DEVICE
     w.close()
+
+
+def test_headers_are_valid_c99(tmp_path):
+    """include/*.h must be consumable from plain C (the FFI layer of a Rust/Go host sees exactly this)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c_abi_consumer.c")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], check=True)

@@ -176,3 +176,20 @@ def test_tile_geometry_does_not_change_the_image(mlrt, monkeypatch):
     for img in images[1:]:
         assert np.array_equal(img, images[0])
     w.close()
+
+
+def test_plain_c_consumer_links_and_renders(mlrt, tmp_path):
+    """A C99 program using only include/*.h and libmlrt_hip.so produces the image the Python path produces."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_consumer")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_consumer.c"), "-o", exe,
+                    "-L", os.path.dirname(mlrt.LIB_PATH), "-lmlrt_hip", "-lm", "-Wl,-rpath," + os.path.dirname(mlrt.LIB_PATH)], check=True)
+    out = subprocess.run([exe, "120", "4", "42"], capture_output=True, text=True, check=True)
+    lines = out.stdout.split("\n")
+    assert lines[:3] == ["P3", "120 80", "255"]
+    px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 120 * 80]], dtype=np.int32).reshape(80, 120, 3)[::-1]
+    w = mlrt.World("random", 42)
+    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 120, 80, 4))
+    assert np.array_equal(px, r.render())
+    r.close()
+    w.close()
