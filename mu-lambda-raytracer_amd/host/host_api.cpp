@@ -83,20 +83,37 @@ void mlrt_camera_new(const double lookfrom[3], const double lookat[3], const dou
 
 int32_t mlrt_image_height(int32_t image_width, double aspect_ratio) { return (int32_t)((double)image_width / aspect_ratio); }  // main.rs:121
 
-int32_t mlrt_write_p3(FILE* f, const int32_t* rgb, int32_t width, int32_t height) {  // main.rs:144,175-179
+// main.rs:144,175-179.  The reference prints one `println!` per pixel (11 MB of text for 1200x800, slower than the GPU
+// render); here every row is formatted into one buffer with a 0..255 lookup table and written at once.
+static void format_rows(std::string& buf, const int32_t* rgb, int32_t width, int32_t row) {
+    static char lut[256][4];
+    static int lut_len[256];
+    static bool ready = false;
+    if (!ready) {
+        for (int v = 0; v < 256; v++) lut_len[v] = std::snprintf(lut[v], sizeof lut[v], "%d", v);
+        ready = true;
+    }
+    const int32_t* p = &rgb[(size_t)row * width * 3];
+    for (int32_t i = 0; i < width; i++, p += 3) {
+        for (int c = 0; c < 3; c++) {
+            const int32_t v = p[c];
+            if (v >= 0 && v < 256) buf.append(lut[v], (size_t)lut_len[v]);
+            else buf.append(std::to_string(v));  // not produced by to_rgb, but the format is "{}" of an i32
+            buf.push_back(c == 2 ? '\n' : ' ');
+        }
+    }
+}
+int32_t mlrt_write_p3(FILE* f, const int32_t* rgb, int32_t width, int32_t height) {
     if (!f || !rgb) { mlrt::set_last_error("mlrt_write_p3: NULL argument"); return MLRT_ERR_INVALID; }
     std::fprintf(f, "P3\n%d %d\n255\n", width, height);
     std::string buf;
-    buf.reserve((size_t)width * 12 + 16);
+    buf.reserve((size_t)width * 12 * 16 + 64);
     for (int32_t j = height - 1; j >= 0; j--) {
-        buf.clear();
-        for (int32_t i = 0; i < width; i++) {
-            const int32_t* p = &rgb[((size_t)j * width + i) * 3];
-            char tmp[48];
-            const int n = std::snprintf(tmp, sizeof tmp, "%d %d %d\n", p[0], p[1], p[2]);
-            buf.append(tmp, (size_t)n);
+        format_rows(buf, rgb, width, j);
+        if (buf.size() > (1u << 20) || j == 0) {
+            if (std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) { mlrt::set_last_error("mlrt_write_p3: write failed"); return MLRT_ERR_INVALID; }
+            buf.clear();
         }
-        if (std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) { mlrt::set_last_error("mlrt_write_p3: write failed"); return MLRT_ERR_INVALID; }
     }
     return MLRT_OK;
 }

@@ -129,8 +129,8 @@ int main(int argc, char** argv) {
     const int32_t precision = opt["precision"] == "fp64" ? MLRT_PRECISION_FP64 : MLRT_PRECISION_FP32;
     std::vector<int32_t> rgb((size_t)params.image_width * params.image_height * 3);
 
-    // do_tracing, main.rs:134-180
-    std::printf("P3\n%d %d\n255\n", params.image_width, params.image_height);
+    // do_tracing, main.rs:134-180.  (The reference prints the header before rendering; mlrt_write_p3 emits header and
+    // pixels together after it - same bytes on stdout.)
     Progress progress;
     progress.start = std::chrono::steady_clock::now();
     mlrt_context* ctx = nullptr;
@@ -138,12 +138,7 @@ int main(int argc, char** argv) {
     if (mlrt_context_render(ctx, &camera, &params, nullptr, 0, rgb.data(), on_progress, &progress) != MLRT_OK) return fail("render");
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - progress.start).count();
     std::fprintf(stderr, "\nRendered in %.3fs\n", secs);
-    // the header is already printed; emit the rows top to bottom (main.rs:175-179)
-    for (int32_t j = params.image_height - 1; j >= 0; j--)
-        for (int32_t i = 0; i < params.image_width; i++) {
-            const int32_t* p = &rgb[((size_t)j * params.image_width + i) * 3];
-            std::printf("%d %d %d\n", p[0], p[1], p[2]);
-        }
+    if (mlrt_write_p3(stdout, rgb.data(), params.image_width, params.image_height) != MLRT_OK) return fail("write");
     mlrt_context_destroy(ctx);
     mlrt_world_free(world);
     return 0;
