@@ -16,14 +16,17 @@
 #include "mlrt_device.hpp"
 
 extern "C" {
-int mlrt_launch_f32(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
-int mlrt_launch_f64(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
-int mlrt_block_threads_f32(void);
-int mlrt_block_threads_f64(void);
+// variant: 0 = FULL (every feature), 1 = LEAN (see mlrt_kernel.hip)
+int mlrt_launch_f32(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
+int mlrt_launch_f64(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
+uint32_t mlrt_variant_features_f32(int variant);
+uint32_t mlrt_variant_features_f64(int variant);
+int mlrt_block_threads_f32(int variant);
+int mlrt_block_threads_f64(int variant);
 int mlrt_acc_bytes_per_wave_f32(void);
 int mlrt_acc_bytes_per_wave_f64(void);
-int mlrt_occupancy_f32(int lds_scene, size_t dyn_lds);
-int mlrt_occupancy_f64(int lds_scene, size_t dyn_lds);
+int mlrt_occupancy_f32(int variant, int lds_scene, size_t dyn_lds);
+int mlrt_occupancy_f64(int variant, int lds_scene, size_t dyn_lds);
 }
 
 namespace mlrt {
@@ -100,6 +103,24 @@ void validate(const mlrt_scene& s) {
         else if (o.kind == MLRT_OBJ_MEDIUM) MLRT_REQUIRE(prim_ok(o.prim) && mat_ok(o.phase_material), "medium boundary/material out of range");
         else MLRT_REQUIRE(false, "unknown object kind");
     }
+}
+
+// Which kernel features the scene needs (mlrt_device.hpp FEAT_*).
+uint32_t scene_features(const mlrt_scene& s) {
+    uint32_t f = 0;
+    if (s.n_boxes > 0) f |= FEAT_BOX;
+    if (s.n_rects > 0) f |= FEAT_RECT;
+    for (int i = 0; i < s.n_objects; i++) {
+        if (s.objects[i].kind == MLRT_OBJ_MEDIUM) f |= FEAT_MEDIUM;
+        if (s.objects[i].transform >= 0) f |= FEAT_XFORM;
+    }
+    for (int i = 0; i < s.n_materials; i++) if (s.materials[i].kind == MLRT_MAT_ISOTROPIC) f |= FEAT_MEDIUM;
+    for (int i = 0; i < s.n_textures; i++) {
+        if (s.textures[i].kind == MLRT_TEX_IMAGE) f |= FEAT_TEX_IMAGE;
+        if (s.textures[i].kind == MLRT_TEX_NOISE) f |= FEAT_TEX_NOISE;
+        if (s.textures[i].kind == MLRT_TEX_CHECKER) f |= FEAT_TEX_CHECKER;
+    }
+    return f;
 }
 
 bool texture_needs_uv(const mlrt_scene& s, int32_t tex, int depth) {
@@ -439,6 +460,8 @@ struct mlrt_context {
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_acc = nullptr;  // frame accumulation buffer, grown on demand
     size_t acc_elems = 0;
+    int32_t variant = 0;  // kernel variant (0 FULL, 1 LEAN)
+    uint32_t features = 0;
     bool lds_scene = false;
     size_t dyn_lds = 0;
     int32_t block_threads = 0, blocks_per_cu = 1, last_grid = 0;
@@ -545,12 +568,12 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
         KParams<float> K{};
         fill_params<float>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
         grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
-        rc = mlrt_launch_f32(&K, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+        rc = mlrt_launch_f32(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
     } else {
         KParams<double> K{};
         fill_params<double>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
         grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
-        rc = mlrt_launch_f64(&K, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+        rc = mlrt_launch_f64(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
     }
     if (rc != 0) throw Fail{MLRT_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)};
     MLRT_HIP(hipEventRecord(c->ev_stop, stream));
@@ -603,6 +626,10 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         hipDeviceProp_t prop;
         MLRT_HIP(hipGetDeviceProperties(&prop, device));
         c->n_cus = prop.multiProcessorCount;
+        // the leanest compiled kernel variant that covers the scene's features (MLRT_FORCE_FULL: experiment hook)
+        c->features = scene_features(*scene);
+        const uint32_t lean = precision == MLRT_PRECISION_FP32 ? mlrt_variant_features_f32(1) : mlrt_variant_features_f64(1);
+        c->variant = ((c->features & ~lean) == 0 && std::getenv("MLRT_FORCE_FULL") == nullptr) ? 1 : 0;
         std::vector<unsigned char> blob;
         if (precision == MLRT_PRECISION_FP32) {
             Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr, std::getenv("MLRT_NO_SAH") == nullptr);
@@ -610,14 +637,14 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size();
-            c->block_threads = mlrt_block_threads_f32();
+            c->block_threads = mlrt_block_threads_f32(c->variant);
         } else {
             Packed<double> P = pack<double>(*scene, false, false);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size();
-            c->block_threads = mlrt_block_threads_f64();
+            c->block_threads = mlrt_block_threads_f64(c->variant);
         }
         c->blob_bytes = (int32_t)blob.size();
         MLRT_HIP(hipMalloc(&c->d_blob, blob.size()));
@@ -645,7 +672,7 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         const size_t lds_limit = 160 * 1024;
         c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit && std::getenv("MLRT_NO_LDS") == nullptr;
         c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;
-        const int occ = precision == MLRT_PRECISION_FP32 ? mlrt_occupancy_f32(c->lds_scene, c->dyn_lds) : mlrt_occupancy_f64(c->lds_scene, c->dyn_lds);
+        const int occ = precision == MLRT_PRECISION_FP32 ? mlrt_occupancy_f32(c->variant, c->lds_scene, c->dyn_lds) : mlrt_occupancy_f64(c->variant, c->lds_scene, c->dyn_lds);
         c->blocks_per_cu = occ > 0 ? occ : 1;
         *out = c;
     });

@@ -44,7 +44,14 @@ struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
 static_assert(sizeof(DNode<float>) == 32, "f32 entry must be 32 bytes (two ds_read_b128)");
 static_assert(sizeof(DNode<double>) == 64, "f64 entry is one 64-byte line");
 
-enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8 };  // set on the material kind when its texture chain samples an image
+enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8 };
+
+// Scene features a kernel variant must support (the packer records which ones a scene uses; the launcher picks the
+// leanest compiled variant that covers them: fewer registers -> more waves per SIMD, less dead code in the hot loop).
+enum : uint32_t {
+    FEAT_BOX = 1, FEAT_RECT = 2, FEAT_XFORM = 4, FEAT_MEDIUM = 8, FEAT_TEX_IMAGE = 16, FEAT_TEX_NOISE = 32, FEAT_TEX_CHECKER = 64,
+    FEAT_ALL = 127
+};  // set on the material kind when its texture chain samples an image
 
 template <typename R>
 struct DMaterial {

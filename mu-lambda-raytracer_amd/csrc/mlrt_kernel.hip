@@ -248,11 +248,12 @@ DEV void to_object(const DNode<real>& xf, P3& o, P3& d) {
     if (xf_rotates(xf)) { o = rotate_back(xf, o); d = rotate_back(xf, d); }
 }
 // The ray in the space of the bracket `xf` (entry index, -1 = world).
+template <uint32_t FEAT>
 DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
 #pragma clang fp contract(off)
     Ray r;
     r.o = o; r.d = d;
-    if (xf >= 0) to_object(S.nodes[xf], r.o, r.d);
+    if ((FEAT & FEAT_XFORM) && xf >= 0) to_object(S.nodes[xf], r.o, r.d);
     r.a = dfma(r.d.z, r.d.z, dfma(r.d.y, r.d.y, r.d.x * r.d.x));  // length_squared: x*x + y*y + z*z
     if (kFast) {
         // 1/|d|^2 to f64 accuracy: f32 seed + 2 Newton steps (no f64 divide in the hot path)
@@ -379,11 +380,12 @@ DEV bool rect_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, 
     return true;
 }
 
+template <uint32_t FEAT>
 DEV bool prim_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
     const int kind = n.tag & TAG_KIND_MASK;
     if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
-    if (kind == TAG_BOX) return box_hit(n, slab_ray(r), tmin, tmax, t_out, aux);
-    if (kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
+    if ((FEAT & FEAT_BOX) && kind == TAG_BOX) return box_hit(n, slab_ray(r), tmin, tmax, t_out, aux);
+    if ((FEAT & FEAT_RECT) && kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
     return false;  // TAG_EMPTY: shapes.rs:8-23
 }
 
@@ -400,22 +402,23 @@ struct Cursor {
 
 // Entries that are not plain box tests: primitives with f64 arithmetic, media, transform brackets.  Executed in
 // batches (see the kernel loop), so the long code below is issued for many lanes at once.
+template <uint32_t FEAT>
 DEV void special_entry(const Scene& S, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
     const double t_min = 0.001;  // raytrace.rs:90
     const DNode<real> n = S.nodes[c.node];
     const int kind = n.tag & TAG_KIND_MASK;
-    if (kind == TAG_XFORM || kind == TAG_XFORM_END) {
+    if ((FEAT & FEAT_XFORM) && (kind == TAG_XFORM || kind == TAG_XFORM_END)) {
         c.xf = kind == TAG_XFORM ? c.node : -1;
-        c.sr = slab_ray(local_ray(S, c.xf, o, d));
+        c.sr = slab_ray(local_ray<FEAT>(S, c.xf, o, d));
         c.node += 1;
         return;
     }
-    const Ray r = local_ray(S, c.xf, o, d);
-    if (kind == TAG_MEDIUM) {
+    const Ray r = local_ray<FEAT>(S, c.xf, o, d);
+    if ((FEAT & FEAT_MEDIUM) && kind == TAG_MEDIUM) {
         // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
         const DNode<real> boundary = S.nodes[c.node + 1];
         double t1, t2; int aux = 0;
-        if (prim_hit(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
+        if (prim_hit<FEAT>(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit<FEAT>(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
             t1 = fmax(t1, t_min);
             t2 = fmin(t2, c.closest);
             if (t1 < t2) {
@@ -434,7 +437,7 @@ DEV void special_entry(const Scene& S, Cursor& c, P3 o, P3 d, Rng& g, RngKey key
         return;
     }
     double t; int aux = 0;
-    if (prim_hit(n, r, t_min, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+    if (prim_hit<FEAT>(n, r, t_min, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
     c.node += 1;
 }
 
@@ -471,18 +474,19 @@ DEV real perlin_turbulence(const Scene& S, int table, V3 p) {  // textures.rs:76
     }
     return abs_r(accum);
 }
+template <uint32_t FEAT>
 DEV V3 texture_value(const Scene& S, int tex, real u, real v, V3 p) {
     DTexture<real> t = S.textures[tex];
-    for (int guard = 0; guard < 8 && t.kind == MLRT_TEX_CHECKER; guard++) {  // textures.rs:40-49
+    for (int guard = 0; (FEAT & FEAT_TEX_CHECKER) && guard < 8 && t.kind == MLRT_TEX_CHECKER; guard++) {  // textures.rs:40-49
         const real sines = sin_r((real)5 * p.x) * sin_r((real)5 * p.y) * sin_r((real)5 * p.z);
         t = S.textures[sines < (real)0 ? t.a : t.b];
     }
     if (t.kind == MLRT_TEX_SOLID) return ld3(t.color);
-    if (t.kind == MLRT_TEX_NOISE) {  // textures.rs:163-167
+    if ((FEAT & FEAT_TEX_NOISE) && t.kind == MLRT_TEX_NOISE) {  // textures.rs:163-167
         const real x = (real)1 + sin_r(t.scale * p.z + (real)10 * perlin_turbulence(S, t.a, t.scale * p));
         return mk((real)0.5 * x, (real)0.5 * x, (real)0.5 * x);
     }
-    if (t.kind == MLRT_TEX_IMAGE) {  // image_texture.rs:16-28
+    if ((FEAT & FEAT_TEX_IMAGE) && t.kind == MLRT_TEX_IMAGE) {  // image_texture.rs:16-28
         const DImage im = S.images[t.a];
         const real uc = min_r(max_r(u, (real)0), (real)1);
         const real vc = min_r(max_r((real)1 - v, (real)0), (real)1);
@@ -528,6 +532,7 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
 
 // Evaluate the closest hit the cursor found and the material response.  Returns true when the path continues with
 // (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
+template <uint32_t FEAT>
 DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
     const DNode<real> n = S.nodes[c.hit_node];
     const int kind = n.tag & TAG_KIND_MASK;
@@ -537,24 +542,24 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     bool front_face = true;
     const int mat_id = n.link;
     const V3 dw = to_v3(d);  // world direction in shading precision
-    if (kind == TAG_MEDIUM) {  // volumes.rs:55-63
+    if ((FEAT & FEAT_MEDIUM) && kind == TAG_MEDIUM) {  // volumes.rs:55-63
         p = o + c.closest * d;
         normal = mk((real)1, (real)0, (real)0);
     } else {
         P3 oo = o, od = d;
         DNode<real> xf;
         xf.tag = 0;
-        if (c.hit_xf >= 0) { xf = S.nodes[c.hit_xf]; to_object(xf, oo, od); }
+        if ((FEAT & FEAT_XFORM) && c.hit_xf >= 0) { xf = S.nodes[c.hit_xf]; to_object(xf, oo, od); }
         const P3 po = oo + c.closest * od;  // Ray::at
         const V3 odf = to_v3(od);
-        V3 outward;
+        V3 outward = mk(0, 0, 1);
         if (kind == TAG_SPHERE) {
             if (kFast) outward = to_v3(po - mkp((double)n.v[0], (double)n.v[1], (double)n.v[2])) * fast_rcp(n.v[3]);
             else outward = mk((real)((po.x - (double)n.v[0]) / (double)n.v[3]), (real)((po.y - (double)n.v[1]) / (double)n.v[3]), (real)((po.z - (double)n.v[2]) / (double)n.v[3]));
-            if (S.materials[mat_id].kind & MATFLAG_NEEDS_UV) sphere_uv(outward, u, v);
-        } else if (kind == TAG_BOX) {
+            if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) sphere_uv(outward, u, v);
+        } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
             outward = axis_vec(c.hit_aux, (real)1);
-        } else {
+        } else if (FEAT & FEAT_RECT) {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);
             u = div_r((real)compp(po, a0) - n.v[0], n.v[1] - n.v[0]);
@@ -563,7 +568,7 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         front_face = dot(outward, odf) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
         normal = front_face ? outward : -outward;
         p = po;
-        if (c.hit_xf >= 0) {
+        if ((FEAT & FEAT_XFORM) && c.hit_xf >= 0) {
             if (xf_rotates(xf)) {  // Rotate::hit, transforms.rs:134-139 (quirk Q10: world normal vs object-space ray)
                 p = rotate_fwd(xf, p);
                 const V3 nw = to_v3(rotate_fwd(xf, to_p3(normal)));
@@ -583,13 +588,13 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
     // volumes.rs:79): drawn here, before the material branches, so the Philox refill runs for the whole batch at once.
     V3 s = mk(0, 0, 0);
-    if (mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || mk_kind == MLRT_MAT_ISOTROPIC) s = random_in_unit_sphere(g, key);
+    if (mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC)) s = random_in_unit_sphere(g, key);
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
         if (!(dot(normal, s) > (real)0)) s = -s;  // random_in_hemisphere, vec.rs:36-43
         V3 dir = normal + s;
         const real eps = (real)1e-8;
         if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
-        thr = thr * texture_value(S, m.tex, u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, u, v, pf);
         o = p; d = to_p3(dir);
         return true;
     }
@@ -616,13 +621,13 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         o = p; d = to_p3(dir);
         return true;
     }
-    if (mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
+    if ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
         const V3 dir = s;
-        thr = thr * texture_value(S, m.tex, u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, u, v, pf);
         o = p; d = to_p3(dir);
         return true;
     }
-    emitted = texture_value(S, m.tex, u, v, pf);  // DiffuseLight, materials.rs:119-127
+    emitted = texture_value<FEAT>(S, m.tex, u, v, pf);  // DiffuseLight, materials.rs:119-127
     return false;
 }
 
@@ -687,8 +692,8 @@ enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  /
 // SPECIAL and SHADE work is executed only when at least MLRT_T_* lanes are parked on it (or nothing else can
 // run), so the long divergent code paths are issued for many lanes at once while the short traversal step keeps
 // most lanes busy every iteration.  Lanes never wait for the slowest ray of a "bounce".
-template <bool LDS_SCENE>
-__global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<real> P) {
+template <bool LDS_SCENE, uint32_t FEAT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
         const uint4* src = reinterpret_cast<const uint4*>(P.blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         const int n16 = P.blob_bytes >> 4;
-        for (int i = threadIdx.x; i < n16; i += MLRT_BLOCK) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
         __syncthreads();
         base = smem;
         acc_base = smem + P.blob_bytes;
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                 const int kind = n.tag & TAG_KIND_MASK;
                 if (kind == TAG_INNER) {
                     c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
-                } else if (kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
+                } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
                     double t; int aux = 0;
                     if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
                     c.node += 1;
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
         if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
             if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
             if (phase == PH_SPECIAL) {
-                special_entry(S, c, o, d, g, key);
+                special_entry<FEAT>(S, c, o, d, g, key);
                 phase = PH_TRAV;
             }
         }
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(MLRT_BLOCK) void mlrt_render_kernel(const KParams<r
                 bool done = true;
                 if (c.hit_node >= 0) {
                     V3 emitted = mk(0, 0, 0);
-                    if (shade(S, c, o, d, thr, emitted, g, key)) {
+                    if (shade<FEAT>(S, c, o, d, thr, emitted, g, key)) {
                         depth--;
                         if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
                     } else {
@@ -924,16 +929,39 @@ __global__ void mlrt_resolve_kernel(const unsigned long long* acc, int n, int sp
 
 // ---------------------------------------------------------------------------------------------- launcher
 
-extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream) {
-    const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
-    hipError_t e;
-    if (lds_scene) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&MLRT_NS::mlrt_render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+// Kernel variants: FULL supports every scene; LEAN is for scenes of spheres with solid-colour materials only (the
+// `random` / `simple` worlds): 127 VGPRs instead of 168, so 1024-thread workgroups run at 4 waves per SIMD.
+#ifndef MLRT_LEAN_BLOCK
+#define MLRT_LEAN_BLOCK 1024
+#endif
+namespace MLRT_NS {
+constexpr uint32_t kLeanFeatures = 0;
+template <bool LDS, uint32_t FEAT, int BLOCK>
+int launch_variant(const KParams<real>& P, int grid, size_t dyn_lds, hipStream_t stream) {
+    if (LDS) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlrt_render_kernel<LDS, FEAT, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<true>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
-    } else {
-        hipLaunchKernelGGL(MLRT_NS::mlrt_render_kernel<false>, dim3((unsigned)grid), dim3(MLRT_BLOCK), dyn_lds, stream, P);
     }
+    hipLaunchKernelGGL((mlrt_render_kernel<LDS, FEAT, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), dyn_lds, stream, P);
+    return (int)hipGetLastError();
+}
+template <bool LDS, uint32_t FEAT, int BLOCK>
+int occupancy_variant(size_t dyn_lds) {
+    int blocks = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, mlrt_render_kernel<LDS, FEAT, BLOCK>, BLOCK, dyn_lds);
+    return e == hipSuccess ? blocks : -1;
+}
+}  // namespace MLRT_NS
+
+// variant: 0 = FULL, 1 = LEAN
+extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream) {
+    const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
+    int rc;
+    if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
+                                     : MLRT_NS::launch_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream);
+    else rc = lds_scene ? MLRT_NS::launch_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream)
+                        : MLRT_NS::launch_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream);
+    if (rc != 0) return rc;
     {
         const int n = P.n_rows * P.width * 3;
         const int rgrid = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
@@ -941,11 +969,10 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int lds_
     }
     return (int)hipGetLastError();
 }
-extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(void) { return MLRT_BLOCK; }
+extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
+extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }
 extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(void) { return MLRT_NS::kAccBytesPerWave; }
-extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int lds_scene, size_t dyn_lds) {
-    int blocks = 0;
-    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, MLRT_NS::mlrt_render_kernel<true>, MLRT_BLOCK, dyn_lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, MLRT_NS::mlrt_render_kernel<false>, MLRT_BLOCK, dyn_lds);
-    return e == hipSuccess ? blocks : -1;
+extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene, size_t dyn_lds) {
+    if (variant == 1) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds);
+    return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds);
 }
