@@ -58,8 +58,10 @@ def test_fp64_build_equals_oracle(mlrt, oracle, earthmap, name, width, aspect, s
 
 @pytest.mark.parametrize("name,width,aspect,spp", SMALL)
 def test_fp32_build_within_tolerance(mlrt, oracle, earthmap, name, width, aspect, spp):
-    # spp is raised so that the 8-bit quantisation step (1/255 = 3.9e-3) does not dominate the RMSE of a single flipped sample
-    spp = spp * 8
+    # spp is raised so that the 8-bit quantisation step (1/255 = 3.9e-3) does not dominate the RMSE of a single flipped sample.
+    # final_scene: its dense, overlapping foam amplifies f32 shading rounding into rare (unbiased) path flips, an error
+    # that falls like 1/sqrt(spp) - 1.0e-3 at spp 128, 4e-4 at the spp 1000 of BASELINE configs[3] - so it is checked at spp 512.
+    spp = spp * (32 if name == "final_scene" else 8)
     rows = np.arange(0, mlrt.image_height(width, aspect), 3)
     got, ref, info = render_both(mlrt, oracle, name, width, aspect, spp, mlrt.PRECISION_FP32, rows=rows,
                                  earth=earthmap if name in ("earth", "final_scene") else None)
@@ -101,7 +103,7 @@ def test_baseline_config2_rows_at_full_size(mlrt, oracle, precision_name):
 def test_baseline_config4_rows_at_full_size(mlrt, oracle, earthmap, precision_name):
     """BASELINE.json configs[3] geometry (final_scene 800x800: deep BVHs, emissive rect, media, image + noise textures)."""
     precision = mlrt.PRECISION_FP64 if precision_name == "fp64" else mlrt.PRECISION_FP32
-    got, ref, _ = render_both(mlrt, oracle, "final_scene", 800, 1.0, 250, precision, rows=[100, 400, 700], earth=earthmap)
+    got, ref, _ = render_both(mlrt, oracle, "final_scene", 800, 1.0, 500, precision, rows=[100, 400, 700], earth=earthmap)
     frac, rmse, maxdiff = metrics(got, ref)
     if precision_name == "fp64":
         assert frac <= 1e-4, (frac, rmse, maxdiff)
