@@ -1,7 +1,7 @@
 // csrc/mlrt_kernel.hip - the render megakernel for gfx950 (CDNA4, wave64).  Hand-written HIP; no MFMA (branchy
 // intersection arithmetic, not a contraction), no CUDA shims, no second back end.
 //
-// Compiled twice (see mu-lambda-raytracer_amd/build.py):
+// Compiled twice (see mu-lambda-raytracer_amd/build.py), both with -ffp-contract=off:
 //   -DMLRT_REAL=float                        -> fast path:   f64 ray state + sphere quadratic, f32 boxes/rects/shading
 //   -DMLRT_REAL=double -ffp-contract=off     -> parity path: f64 throughout, the reference's operation order
 //

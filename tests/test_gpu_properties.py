@@ -193,3 +193,26 @@ def test_plain_c_consumer_links_and_renders(mlrt, tmp_path):
     assert np.array_equal(px, r.render())
     r.close()
     w.close()
+
+
+@pytest.mark.parametrize("name", ["random", "cornell_smoke", "final_scene"])
+def test_scene_in_hbm_equals_scene_in_lds(mlrt, earthmap, monkeypatch, name):
+    """Scenes larger than the 160 KB of LDS are walked straight from HBM/L2 by the same kernel (template flag); forcing
+    that path (MLRT_NO_LDS) and forcing the FULL kernel variant (MLRT_FORCE_FULL) must not change a single pixel."""
+    w = mlrt.World(name, 42, earthmap if name == "final_scene" else None)
+    cam = mlrt.default_camera(w, 1.0)
+    params = mlrt.make_params(w, 96, 96, 32)
+    r = mlrt.Renderer(w, cam, params)
+    base = r.render()
+    assert r.info()["lds_scene"]
+    r.close()
+    for env in ("MLRT_NO_LDS", "MLRT_FORCE_FULL"):
+        monkeypatch.setenv(env, "1")
+        r = mlrt.Renderer(w, cam, params)
+        img = r.render()
+        if env == "MLRT_NO_LDS":
+            assert not r.info()["lds_scene"]
+        r.close()
+        monkeypatch.delenv(env)
+        assert np.array_equal(img, base), env
+    w.close()
