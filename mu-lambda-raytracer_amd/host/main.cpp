@@ -5,6 +5,12 @@
 // The render itself is mlrt_context_render (include/mlrt.h) on the MI355X; there is no CPU path here.
 // Flags beyond the reference: --precision=fp32|fp64, --device=N, --earthmap=<P6 file> (decoded earthmap.jpg).
 // Not supported: running without --seed and --randomized_rendering (ThreadRng, non-deterministic).
+//
+// Frame-sequence mode (replaces /root/reference/movie.py, which re-launches the binary - world rebuild and all - once
+// per frame): --movie_frames=N [--movie_step_degrees=0.5] [--movie_origin=x,y,z] [--movie_prefix=_movie/frame] renders N
+// frames with the camera orbiting `movie_origin` exactly as movie.py:56-69 moves it (lookat = origin, lookfrom = origin +
+// the start offset with its polar angle advanced by step degrees per frame) and writes <prefix>NNNN.ppm.  The world,
+// the packed scene and the device context stay resident; only the camera changes.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -128,6 +134,41 @@ int main(int argc, char** argv) {
 
     const int32_t precision = opt["precision"] == "fp64" ? MLRT_PRECISION_FP64 : MLRT_PRECISION_FP32;
     std::vector<int32_t> rgb((size_t)params.image_width * params.image_height * 3);
+
+    if (opt.count("movie_frames")) {
+        const int frames = std::atoi(opt["movie_frames"].c_str());
+        const double step_grad = opt.count("movie_step_degrees") ? std::atof(opt["movie_step_degrees"].c_str()) : 0.5;  // movie.py:10
+        double origin[3] = {278.0, 278.0, 400.0};                                                                       // movie.py:56
+        if (opt.count("movie_origin") && !parse_vector(opt["movie_origin"], origin)) { std::fprintf(stderr, "mlrt: bad --movie_origin\n"); return 2; }
+        const std::string prefix = opt.count("movie_prefix") ? opt["movie_prefix"] : "_movie/frame";
+        // movie.py:57-60: delta = start - origin in polar form (r, theta, phi); `start` is the camera position
+        const double dx = lookfrom[0] - origin[0], dy = lookfrom[1] - origin[1], dz = lookfrom[2] - origin[2];
+        const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
+        double theta = std::atan2(std::sqrt(dx * dx + dy * dy), dz);
+        const double phi = std::atan2(dy, dx);
+        const double grad = 3.141592653589793 / 180.0;  // movie.py:62 (math.pi)
+        mlrt_context* mctx = nullptr;
+        if (mlrt_context_create(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &mctx) != MLRT_OK) return fail("context");
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < frames; i++) {
+            // movie.py:41-46 polar_to_cart, :64-69
+            const double from[3] = {origin[0] + r * std::cos(phi) * std::sin(theta), origin[1] + r * std::sin(phi) * std::sin(theta), origin[2] + r * std::cos(theta)};
+            double fd = focus_dist;
+            if (!opt.count("focus_dist")) { const double ex = origin[0] - from[0], ey = origin[1] - from[1], ez = origin[2] - from[2]; fd = std::sqrt(ex * ex + ey * ey + ez * ez); }
+            mlrt_camera cam_i;
+            mlrt_camera_new(from, origin, up, fov, aspect_ratio, std::atof(opt["aperture"].c_str()), fd, &cam_i);
+            if (mlrt_context_render(mctx, &cam_i, &params, nullptr, 0, rgb.data(), nullptr, nullptr) != MLRT_OK) return fail("render");
+            char name[512];
+            std::snprintf(name, sizeof name, "%s%04d.ppm", prefix.c_str(), i);
+            if (mlrt_write_p3_path(name, rgb.data(), params.image_width, params.image_height) != MLRT_OK) return fail("write");
+            std::fprintf(stderr, "Frame %d: (%.17g, %.17g, %.17g)\n", i, from[0] - origin[0], from[1] - origin[1], from[2] - origin[2]);
+            theta += step_grad * grad;
+        }
+        std::fprintf(stderr, "Rendered %d frames in %.3fs\n", frames, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        mlrt_context_destroy(mctx);
+        mlrt_world_free(world);
+        return 0;
+    }
 
     // do_tracing, main.rs:134-180.  (The reference prints the header before rendering; mlrt_write_p3 emits header and
     // pixels together after it - same bytes on stdout.)

@@ -216,3 +216,24 @@ def test_scene_in_hbm_equals_scene_in_lds(mlrt, earthmap, monkeypatch, name):
         monkeypatch.delenv(env)
         assert np.array_equal(img, base), env
     w.close()
+
+
+def test_movie_mode_equals_one_process_per_frame(mlrt, tmp_path):
+    """Frame-sequence mode (the replacement of the reference's movie.py loop) renders what separate invocations with
+    movie.py's --lookat/--lookfrom arguments render, with the scene and the context kept resident."""
+    from math import atan2, cos, pi, sin, sqrt
+    earth = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "earthmap.ppm")
+    common = ["--world=final_scene", "--seed=42", "--aspect_ratio=1:1", "--image_width=64", "--samples_per_pixel=4", "--earthmap=" + earth]
+    prefix = str(tmp_path / "frame")
+    subprocess.run([mlrt.CLI_PATH] + common + ["--movie_frames=3", "--movie_prefix=" + prefix], check=True, capture_output=True)
+    # movie.py:35-69
+    origin, start = (278, 278, 400), (478, 278, -600)
+    d = tuple(a - b for a, b in zip(start, origin))
+    r, theta, phi = sqrt(sum(c * c for c in d)), atan2(sqrt(d[0] ** 2 + d[1] ** 2), d[2]), atan2(d[1], d[0])
+    for i in range(3):
+        c = (r * cos(phi) * sin(theta), r * sin(phi) * sin(theta), r * cos(theta))
+        lookfrom = tuple(a + b for a, b in zip(origin, c))
+        one = subprocess.run([mlrt.CLI_PATH] + common + ["--lookat={},{},{}".format(*origin), "--lookfrom={},{},{}".format(*lookfrom)],
+                             check=True, capture_output=True, text=True).stdout
+        assert open(prefix + "%04d.ppm" % i).read() == one, i
+        theta += 0.5 * pi / 180
