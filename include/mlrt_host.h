@@ -7,6 +7,7 @@
  *   mlrt_image_height   <- (image_width as f64 / aspect_ratio) as usize  (src/main.rs:121)
  *   mlrt_write_p3       <- the PPM printer                               (src/main.rs:144,175-179)
  *   mlrt_pcg64_*        <- SeedableRngator::rng = Pcg64::seed_from_u64(seed + site)  (src/rngator.rs:27-31)
+ *   mlrt_decode_jpeg*   <- image::open("earthmap.jpg") + to_rgb8()                   (src/worlds.rs:180-181, 441-442)
  *
  * The world builders replay the reference's scene RNG stream draw for draw (rng(0), main.rs:185), so the
  * scene at a given --seed is the reference's scene; the BVH topology is the reference's too (bhv.rs:122-145).
@@ -51,6 +52,12 @@ int32_t mlrt_write_p3(FILE* f, const int32_t* rgb, int32_t width, int32_t height
 int32_t mlrt_write_p3_path(const char* path, const int32_t* rgb, int32_t width, int32_t height);
 
 void mlrt_pcg64_stream(uint64_t seed, uint64_t site_id, int32_t n, uint64_t* out);
+
+/* Baseline (sequential Huffman, 8-bit, 1 or 3 components) JPEG -> RGB8, row 0 = top.  *rgb_out is malloc'ed by the
+ * library: release it with mlrt_free.  Progressive / arithmetic files return MLRT_ERR_UNSUPPORTED. */
+int32_t mlrt_decode_jpeg(const uint8_t* data, int64_t size, uint8_t** rgb_out, int32_t* width, int32_t* height);
+int32_t mlrt_decode_jpeg_file(const char* path, uint8_t** rgb_out, int32_t* width, int32_t* height);
+void mlrt_free(void* p);
 
 #ifdef __cplusplus
 }

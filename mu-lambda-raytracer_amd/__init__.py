@@ -109,7 +109,7 @@ EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_
                   "mlrt_context_render_device", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_render"]
 EXPORTS_MLRT_HOST_H = ["mlrt_world_count", "mlrt_world_name", "mlrt_world_build", "mlrt_world_free", "mlrt_world_scene", "mlrt_world_camera",
                        "mlrt_world_background", "mlrt_world_stream_probes", "mlrt_camera_new", "mlrt_image_height", "mlrt_write_p3",
-                       "mlrt_write_p3_path", "mlrt_pcg64_stream"]
+                       "mlrt_write_p3_path", "mlrt_pcg64_stream", "mlrt_decode_jpeg", "mlrt_decode_jpeg_file", "mlrt_free"]
 
 _lib = None
 
@@ -135,6 +135,9 @@ def lib():
         L.mlrt_image_height.argtypes = [C.c_int32, C.c_double]
         L.mlrt_write_p3_path.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mlrt_pcg64_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]
+        L.mlrt_decode_jpeg.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.mlrt_decode_jpeg_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.mlrt_free.argtypes = [C.c_void_p]
         L.mlrt_context_create.argtypes = [C.POINTER(Scene), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.mlrt_context_destroy.argtypes = [C.c_void_p]
         L.mlrt_context_render.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -168,6 +171,16 @@ def load_earthmap(path=EARTHMAP_PPM):
         w, h = [int(x) for x in f.readline().split()]
         assert f.readline().strip() == b"255"
         return np.frombuffer(f.read(w * h * 3), dtype=np.uint8).reshape(h, w, 3).copy()
+
+
+def decode_jpeg(data):
+    """Baseline JPEG bytes -> uint8 [H][W][3] through the library's own reader (mlrt_decode_jpeg)."""
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    out, w, h = C.POINTER(C.c_uint8)(), C.c_int32(), C.c_int32()
+    _check(lib().mlrt_decode_jpeg(buf, len(data), C.byref(out), C.byref(w), C.byref(h)))
+    img = np.ctypeslib.as_array(out, shape=(h.value, w.value, 3)).copy()
+    lib().mlrt_free(out)
+    return img
 
 
 def image_height(image_width, aspect_ratio):

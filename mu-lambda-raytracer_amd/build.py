@@ -38,6 +38,7 @@ UNITS = [
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),
     ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),
+    ("jpeg.o", os.path.join(HERE, "host", "jpeg_baseline.cpp"), ["-ffp-contract=off"]),
 ]
 HEADERS = [os.path.join(ROOT, "include", "mlrt.h"), os.path.join(ROOT, "include", "mlrt_host.h"), os.path.join(HERE, "csrc", "mlrt_device.hpp"),
            os.path.join(HERE, "host", "host_internal.hpp"), os.path.join(HERE, "host", "pcg64.hpp"), os.path.abspath(__file__)]

@@ -3,7 +3,8 @@
 // Mirrors /root/reference/src/main.rs: args() :64-132 (same flag names and defaults), do_it() :181-207 (world from
 // rng(0), camera), do_tracing() :134-180 (P3 header, render, "Rendered in X s" on stderr, rows top to bottom).
 // The render itself is mlrt_context_render (include/mlrt.h) on the MI355X; there is no CPU path here.
-// Flags beyond the reference: --precision=fp32|fp64, --device=N, --earthmap=<P6 file> (decoded earthmap.jpg).
+// Flags beyond the reference: --precision=fp32|fp64, --device=N, --earthmap=<earthmap.jpg or a binary P6> (default:
+// earthmap.jpg in the working directory, as the reference; then earthmap.ppm).
 // Not supported: running without --seed and --randomized_rendering (ThreadRng, non-deterministic).
 //
 // Frame-sequence mode (replaces /root/reference/movie.py, which re-launches the binary - world rebuild and all - once
@@ -70,7 +71,7 @@ int fail(const char* what) {
 int main(int argc, char** argv) {
     std::map<std::string, std::string> opt = {{"aspect_ratio", "16:9"}, {"image_width", "400"}, {"samples_per_pixel", "200"}, {"max_depth", "50"},
                                               {"up", "0,1.0,0"},        {"aperture", "0.0"},    {"world", "simple"},          {"precision", "fp32"},
-                                              {"device", "0"},          {"earthmap", "earthmap.ppm"}};
+                                              {"device", "0"}};
     for (int i = 1; i < argc; i++) {
         std::string a(argv[i]);
         if (a == "--randomized_rendering" || a == "-r") { std::fprintf(stderr, "mlrt: --randomized_rendering (ThreadRng) is not supported by the device path\n"); return 2; }
@@ -107,8 +108,24 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> earth;
     int ew = 0, eh = 0;
     if (opt["world"] == "earth" || opt["world"] == "final_scene") {
-        if (!read_p6(opt["earthmap"], earth, ew, eh)) {
-            std::fprintf(stderr, "mlrt: cannot read the decoded earth map (binary P6) at '%s'; see assets/earthmap.ppm\n", opt["earthmap"].c_str());
+        // worlds.rs:180,441: image::open("earthmap.jpg") relative to the working directory.  --earthmap overrides the
+        // path; a .ppm (binary P6, e.g. assets/earthmap.ppm) is accepted as well.
+        const bool given = opt.count("earthmap") != 0;
+        const std::string path = given ? opt["earthmap"] : "earthmap.jpg";
+        const bool is_ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
+        bool ok = false;
+        if (is_ppm) ok = read_p6(path, earth, ew, eh);
+        else {
+            uint8_t* px = nullptr;
+            int32_t w32 = 0, h32 = 0;
+            if (mlrt_decode_jpeg_file(path.c_str(), &px, &w32, &h32) == MLRT_OK) {
+                earth.assign(px, px + (size_t)w32 * h32 * 3);
+                mlrt_free(px);
+                ew = w32; eh = h32; ok = true;
+            } else if (!given && read_p6("earthmap.ppm", earth, ew, eh)) ok = true;
+        }
+        if (!ok) {
+            std::fprintf(stderr, "mlrt: cannot read the earth map at '%s' (%s); pass --earthmap=<earthmap.jpg | assets/earthmap.ppm>\n", path.c_str(), mlrt_last_error());
             return 2;
         }
     }
