@@ -103,15 +103,14 @@ def main():
     d_rows = torch.tensor(my_rows, dtype=torch.int32, device=dev)
     d_rgb = torch.zeros((len(my_rows), W, 3), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
+    gather_device = torch.device("cpu") if (args.backend == "gloo" and world_size > 1) else dev  # gloo: rehearsal only
+    gatherer = rowtile.RowGatherer(H, W, rank, world_size, gather_device)
     frame = {}
 
     def step():
         renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
         # the one collective of the path: finished rows to rank 0 over xGMI (a plain scatter into the frame at N = 1)
-        rows_u8 = d_rgb.to(torch.uint8)
-        if args.backend == "gloo" and world_size > 1:
-            rows_u8 = rows_u8.cpu()  # rehearsal only
-        frame["image"] = rowtile.gather_rows(rows_u8, H, rank, world_size)
+        frame["image"] = gatherer.gather(d_rgb if gather_device == dev else d_rgb.cpu())
 
     def barrier():
         if world_size > 1:

@@ -30,6 +30,9 @@ rows = np.array(rowtile.rows_for_rank(H, rank, world), dtype=np.int32)
 rgb, _, _, _ = ow.render(cam, W, H, spp, seed=seed, rng_mode=oracle_binding.RNG_PHILOX_SAMPLE, rows=rows, threads=2)
 local = torch.from_numpy(np.stack([rgb[j] for j in rows]).astype(np.uint8))
 image = rowtile.gather_rows(local, H, rank, world)
+image2 = rowtile.RowGatherer(H, W, rank, world, torch.device('cpu')).gather(torch.from_numpy(np.stack([rgb[j] for j in rows]).astype(np.int32)))
+if rank == 0:
+    assert torch.equal(image, image2)
 if rank == 0:
     np.save(sys.argv[2], image.numpy())
 dist.barrier()
