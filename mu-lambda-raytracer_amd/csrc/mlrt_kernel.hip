@@ -212,8 +212,15 @@ struct Scene {
 
 // What the cheap per-step tests need of the ray in the current (world or object) space.
 struct SlabRay {
-    V3 of, invd;   // fast build: (float)origin and 1/(float)direction; parity build: origin and direction
+    V3 of, invd;   // fast build: -(float)origin/(float)direction and 1/(float)direction; parity build: origin and direction
 };
+// t = (k - origin) / direction for a plane coordinate k.  Fast build: ONE explicit fma per plane, k * (1/d) + (-o/d) (the
+// explicit builtin keeps the rounding independent of the compiler's contraction setting); parity build: the reference's
+// subtraction and division (bhv.rs:33-35).
+DEV real slab_t(real k, real of, real invd) {
+    if (kFast) return (real)__builtin_fmaf((float)k, (float)invd, (float)of);
+    return (k - of) / invd;
+}
 // The f64 ray for the primitive tests.
 struct Ray {
     P3 o, d;
@@ -269,23 +276,28 @@ DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
 DEV SlabRay slab_ray(const Ray& r) {
     SlabRay q;
     q.of = to_v3(r.o);
-    if (kFast) q.invd = mk(fast_rcp((real)r.d.x), fast_rcp((real)r.d.y), fast_rcp((real)r.d.z));
-    else q.invd = to_v3(r.d);
+    if (kFast) {
+        // an axis-parallel ray (d = 0 on an axis) keeps finite terms: |d| is floored at 1e-30, so t stays +-1e30-sized
+        // with the right sign instead of inf - inf
+        const float tiny = 1e-30f;
+        const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+        q.invd = mk(fast_rcp((real)(fabsf(dx) < tiny ? copysignf(tiny, dx) : dx)), fast_rcp((real)(fabsf(dy) < tiny ? copysignf(tiny, dy) : dy)),
+                    fast_rcp((real)(fabsf(dz) < tiny ? copysignf(tiny, dz) : dz)));
+        q.of = mk(-(q.of.x * q.invd.x), -(q.of.y * q.invd.y), -(q.of.z * q.invd.z));
+    } else {
+        q.invd = to_v3(r.d);
+    }
     return q;
 }
 
 // AABB::hit, bhv.rs:29-42 (quirk Q5).  Evaluating the three slabs and testing once equals the reference's
 // per-axis early exit because the interval only shrinks.
 DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) {
-    real t0, t1;
-    if (kFast) { t0 = (n.v[0] - r.of.x) * r.invd.x; t1 = (n.v[3] - r.of.x) * r.invd.x; }
-    else { t0 = (n.v[0] - r.of.x) / r.invd.x; t1 = (n.v[3] - r.of.x) / r.invd.x; }
+    real t0 = slab_t(n.v[0], r.of.x, r.invd.x), t1 = slab_t(n.v[3], r.of.x, r.invd.x);
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    if (kFast) { t0 = (n.v[1] - r.of.y) * r.invd.y; t1 = (n.v[4] - r.of.y) * r.invd.y; }
-    else { t0 = (n.v[1] - r.of.y) / r.invd.y; t1 = (n.v[4] - r.of.y) / r.invd.y; }
+    t0 = slab_t(n.v[1], r.of.y, r.invd.y); t1 = slab_t(n.v[4], r.of.y, r.invd.y);
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    if (kFast) { t0 = (n.v[2] - r.of.z) * r.invd.z; t1 = (n.v[5] - r.of.z) * r.invd.z; }
-    else { t0 = (n.v[2] - r.of.z) / r.invd.z; t1 = (n.v[5] - r.of.z) / r.invd.z; }
+    t0 = slab_t(n.v[2], r.of.z, r.invd.z); t1 = slab_t(n.v[5], r.of.z, r.invd.z);
     tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
     // fast build: 2-ulp slack on the far bound keeps the f32 cull conservative against the f64 hit distance
 #ifndef MLRT_NO_ROBUST
@@ -342,9 +354,7 @@ DEV bool box_hit(const DNode<real>& n, const SlabRay& r, double tmin, double tma
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const real oa = comp(r.of, a), ia = comp(r.invd, a);
-        real t0, t1;
-        if (kFast) { t0 = (n.v[a] - oa) * ia; t1 = (n.v[3 + a] - oa) * ia; }
-        else { t0 = (n.v[a] - oa) / ia; t1 = (n.v[3 + a] - oa) / ia; }
+        const real t0 = slab_t(n.v[a], oa, ia), t1 = slab_t(n.v[3 + a], oa, ia);
         lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
     }
     real te = lo[0]; int ae = 0;

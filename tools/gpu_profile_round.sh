@@ -13,7 +13,7 @@ for name in ("fetch", "write"):
     tot = 0.0; n = 0
     for f in glob.glob("gpurun_out/prof_$R/%s/*counter_collection.csv" % name):
         for r in csv.DictReader(open(f)):
-            if "mlrt" in r["Kernel_Name"]:
+            if "mlrt_render_kernel" in r["Kernel_Name"]:
                 tot += float(r["Counter_Value"]); n += 1
     out[name + "_size_kb_per_launch"] = tot
 # gfx950: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): the scene blob is staged with 16 B/lane loads
