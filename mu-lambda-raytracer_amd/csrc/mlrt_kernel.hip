@@ -413,9 +413,8 @@ struct Cursor {
 // Entries that are not plain box tests: primitives with f64 arithmetic, media, transform brackets.  Executed in
 // batches (see the kernel loop), so the long code below is issued for many lanes at once.
 template <uint32_t FEAT>
-DEV void special_entry(const Scene& S, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
+DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
     const double t_min = 0.001;  // raytrace.rs:90
-    const DNode<real> n = S.nodes[c.node];
     const int kind = n.tag & TAG_KIND_MASK;
     if ((FEAT & FEAT_XFORM) && (kind == TAG_XFORM || kind == TAG_XFORM_END)) {
         c.xf = kind == TAG_XFORM ? c.node : -1;
@@ -695,6 +694,15 @@ DEV unsigned long long to_fixed(real c) {
 #endif
 enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  // WAIT: no sample to be had until a bank of the ring drains
 
+// The traversal is latency bound (rocprof: waves wait on LDS 40 % of their cycles at 4 waves per SIMD), so the entry for
+// a lane's NEXT step is fetched in ONE round trip (both 16-byte halves, all lanes, clamped index) right after the cursor
+// moved, and the batch bookkeeping runs while it is in flight.  pin_entry marks where it must have arrived, which also
+// stops the compiler from sinking the loads behind the tag test (two dependent round trips per step).
+DEV DNode<real> fetch_entry(const Scene& S, int node, int n_nodes) { return S.nodes[node < n_nodes ? node : n_nodes - 1]; }
+DEV void pin_entry(DNode<real>& n) {
+    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]), "+v"(n.v[2]), "+v"(n.v[3]), "+v"(n.v[4]), "+v"(n.v[5]), "+v"(n.link), "+v"(n.tag));
+}
+
 // The megakernel.  Every lane runs a small state machine over its current path:
 //   PH_TRAV    one cheap step per loop iteration: fetch an entry, slab-test it, follow the skip link
 //   PH_SPECIAL parked on an entry that needs the long code (f64 sphere quadratic, rect, medium, transform bracket)
@@ -761,11 +769,12 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
     c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
     c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
 
+    DNode<real> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
     for (;;) {
         // (A) one traversal step
+        pin_entry(n);
         if (phase == PH_TRAV) {
             if (c.node < n_nodes) {
-                const DNode<real> n = S.nodes[c.node];
                 const int kind = n.tag & TAG_KIND_MASK;
                 if (kind == TAG_INNER) {
                     c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
@@ -780,6 +789,7 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
                 phase = PH_SHADE;
             }
         }
+        n = fetch_entry(S, c.node, n_nodes);
         if (P.stats) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); }
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
@@ -787,9 +797,10 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
         if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
             if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
             if (phase == PH_SPECIAL) {
-                special_entry<FEAT>(S, c, o, d, g, key);
+                special_entry<FEAT>(S, n, c, o, d, g, key);
                 phase = PH_TRAV;
             }
+            n = fetch_entry(S, c.node, n_nodes);
         }
         // (C) batched shading, path termination and regeneration
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
@@ -912,6 +923,7 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
                     phase = (queue_done && t_next >= t_total) ? PH_IDLE : PH_WAIT;
                 }
             }
+            n = fetch_entry(S, c.node, n_nodes);
         }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
     }
