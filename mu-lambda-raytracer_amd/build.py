@@ -1,6 +1,10 @@
 """Build libmlrt_hip.so (HIP kernels for gfx950 + C ABI + host mirror) and the `mlrt` CLI, in-tree.
 
-    python mu-lambda-raytracer_amd/build.py [--force]
+    python mu-lambda-raytracer_amd/build.py [--force] [--debug]
+
+--debug builds lib/libmlrt_hip_debug.so next to the release library: the same code with the in-kernel counters
+(MLRT_STATS=1) and the per-sample path printer (MLRT_DEBUG_PIXEL=pixel,sample) compiled in; load it with
+MLRT_LIB=<path>.  The release kernels carry no instrumentation (it costs 8 % even when switched off).
 
 hipcc cross-compiles gfx950 without a GPU.  Outputs: mu-lambda-raytracer_amd/lib/libmlrt_hip.so and
 mu-lambda-raytracer_amd/bin/mlrt (git-ignored, shipped to the GPU box by gpurun).
@@ -13,17 +17,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_DIR = os.path.join(HERE, "lib")
 BIN_DIR = os.path.join(HERE, "bin")
-OBJ_DIR = os.path.join(HERE, "lib", "obj" + os.environ.get("MLRT_TAG", ""))
-LIB = os.path.join(LIB_DIR, "libmlrt_hip%s.so" % os.environ.get("MLRT_TAG", ""))
 CLI = os.path.join(BIN_DIR, "mlrt")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-BLOCK = os.environ.get("MLRT_BLOCK", "768")
 # experiment hooks: MLRT_TAG builds a side-by-side variant (lib/libmlrt_hip<tag>.so, loaded with MLRT_LIB=<path>);
 # MLRT_KERNEL_FLAGS appends flags to the f32 kernel compile (e.g. "-DMLRT_X=1")
+DEBUG = "--debug" in sys.argv
+if DEBUG:
+    os.environ["MLRT_TAG"] = "_debug"
 TAG = os.environ.get("MLRT_TAG", "")
 EXTRA_KERNEL_FLAGS = os.environ.get("MLRT_KERNEL_FLAGS", "").split()
+# the instrumented kernels need the registers the release kernels give up for occupancy: looser launch bounds
+DEBUG_FLAGS = ["-DMLRT_DEBUG_BUILD=1"] if DEBUG else []
+DEBUG_FLAGS_F32 = ["-DMLRT_LEAN_BLOCK=1024", "-DMLRT_LEAN_WAVES_PER_EU=4"] if DEBUG else []
+if DEBUG:
+    os.environ.setdefault("MLRT_BLOCK", "768")
+    os.environ.setdefault("MLRT_FULL_WAVES", "3")
+BLOCK = os.environ.get("MLRT_BLOCK", "1024")
+OBJ_DIR = os.path.join(HERE, "lib", "obj" + TAG)
+LIB = os.path.join(LIB_DIR, "libmlrt_hip%s.so" % TAG)
 
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(ROOT, "include")]
 KERNEL = os.path.join(HERE, "csrc", "mlrt_kernel.hip")
@@ -32,9 +45,9 @@ UNITS = [
     # Both kernel builds pin FMA contraction OFF: every f32/f64 operation is the IEEE operation the source spells out
     # (the f64 geometry code fuses explicitly, see dfma), so the image does not depend on the compiler's inlining or on
     # which kernel variant runs.  Measured cost against -ffp-contract=fast: 1.5 % (C2) to 3.5 % (final_scene).
-    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS),
+    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
     # parity build: no FMA contraction, so every rounding sits where the reference (and the oracle) has it
-    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256", "-ffp-contract=off"]),
+    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256", "-DMLRT_LEAN_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),
     ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),

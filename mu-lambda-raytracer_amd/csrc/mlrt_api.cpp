@@ -19,6 +19,8 @@ extern "C" {
 // variant: 0 = FULL (every feature), 1 = LEAN (see mlrt_kernel.hip)
 int mlrt_launch_f32(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
 int mlrt_launch_f64(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
+int mlrt_instrumented_f32(void);
+int mlrt_instrumented_f64(void);
 uint32_t mlrt_variant_features_f32(int variant);
 uint32_t mlrt_variant_features_f64(int variant);
 int mlrt_block_threads_f32(int variant);
@@ -663,7 +665,11 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             MLRT_HIP(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DImage), hipMemcpyHostToDevice));
         }
         MLRT_HIP(hipMalloc(&c->d_tile_counter, sizeof(unsigned int)));
-        if (std::getenv("MLRT_STATS")) { MLRT_HIP(hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long))); MLRT_HIP(hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long))); }
+        if (std::getenv("MLRT_STATS") || std::getenv("MLRT_DEBUG_PIXEL")) {
+            const bool instrumented = (precision == MLRT_PRECISION_FP64 ? mlrt_instrumented_f64() : mlrt_instrumented_f32()) != 0;
+            if (!instrumented) std::fprintf(stderr, "mlrt: MLRT_STATS / MLRT_DEBUG_PIXEL need the debug build of the library (python mu-lambda-raytracer_amd/build.py --debug; MLRT_LIB=.../libmlrt_hip_debug.so): ignored\n");
+            else if (std::getenv("MLRT_STATS")) { MLRT_HIP(hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long))); MLRT_HIP(hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long))); }
+        }
         MLRT_HIP(hipEventCreate(&c->ev_start));
         MLRT_HIP(hipEventCreate(&c->ev_stop));
         // LDS plan: the f32 blob is staged in LDS when it fits next to the per-wave accumulators
@@ -749,10 +755,10 @@ int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]) {
 }
 
 // Debug only (MLRT_STATS=1; not part of the ABI headers): copies and clears the in-kernel counters.
-int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[8]) {
+int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[16]) {
     if (!ctx || !ctx->d_stats) return MLRT_ERR_UNSUPPORTED;
-    if (hipMemcpy(out, ctx->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MLRT_ERR_HIP;
-    (void)hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long));
+    if (hipMemcpy(out, ctx->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MLRT_ERR_HIP;
+    (void)hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long));
     return MLRT_OK;
 }
 

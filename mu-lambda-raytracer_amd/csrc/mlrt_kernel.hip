@@ -40,6 +40,17 @@
 #define MLRT_BLOCK 512
 #endif
 #define DEV __device__ __forceinline__
+// Instrumentation (in-kernel counters MLRT_STATS=1, the per-sample path printer MLRT_DEBUG_PIXEL=p,s) exists only in the
+// debug build of the library (build.py --debug -> libmlrt_hip_debug.so).  Even switched off at run time it costs the
+// render kernel 8 %: its wave-uniform counters and the printf call's registers push tile and camera state out of the
+// scalar register file.
+#ifdef MLRT_DEBUG_BUILD
+#define MLRT_STATS_ON(P) ((P).stats != nullptr)
+#define MLRT_DEBUG_ON(P) ((P).debug_pixel >= 0)
+#else
+#define MLRT_STATS_ON(P) false
+#define MLRT_DEBUG_ON(P) false
+#endif
 #define MLRT_CAT_(a, b) a##b
 #define MLRT_CAT(a, b) MLRT_CAT_(a, b)
 #ifndef MLRT_SUFFIX
@@ -56,7 +67,10 @@ constexpr bool kFast = sizeof(real) == 4;
 constexpr int kMaxPixPerTile = 4;
 // per wave: a ring of kBanks accumulator banks (tiles in flight: the one being handed out and older ones whose last
 // paths are still running) + remaining / out_base / n_values per bank
-constexpr int kBanks = 8;
+#ifndef MLRT_BANKS
+#define MLRT_BANKS 8
+#endif
+constexpr int kBanks = MLRT_BANKS;
 constexpr int kBankValues = kMaxPixPerTile * 3;
 constexpr int kAccBytesPerWave = kBanks * kBankValues * 8 + kBanks * 12;
 
@@ -154,7 +168,14 @@ DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-DEV void rng_fill(Rng& g, RngKey key, uint32_t block) { philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3); }
+DEV void rng_fill(Rng& g, RngKey key, uint32_t block) {
+    philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3);
+#ifdef MLRT_PROBE_PHILOX  // sensitivity probe (experiments only): the Philox arithmetic twice, result unchanged
+    uint32_t x0, x1, x2, x3;
+    philox4x32_10(key.k0, key.k1, block + 1u, g.sample, g.pixel, 0u, x0, x1, x2, x3);
+    if (g.pixel == 0xFFFFFFFFu) { g.b0 ^= x0; g.b1 ^= x1; g.b2 ^= x2; g.b3 ^= x3; }
+#endif
+}
 DEV uint32_t rng_next(Rng& g, RngKey key) {
     const uint32_t i = g.draw & 3u;
     if (i == 0) rng_fill(g, key, g.draw >> 2);
@@ -710,8 +731,15 @@ DEV void pin_entry(DNode<real>& n) {
 // SPECIAL and SHADE work is executed only when at least MLRT_T_* lanes are parked on it (or nothing else can
 // run), so the long divergent code paths are issued for many lanes at once while the short traversal step keeps
 // most lanes busy every iteration.  Lanes never wait for the slowest ray of a "bounce".
+#ifndef MLRT_LEAN_WAVES_PER_EU
+#define MLRT_LEAN_WAVES_PER_EU 6
+#endif
+#ifndef MLRT_FULL_WAVES_PER_EU
+#define MLRT_FULL_WAVES_PER_EU 1
+#endif
 template <bool LDS_SCENE, uint32_t FEAT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0 ? MLRT_LEAN_WAVES_PER_EU : MLRT_FULL_WAVES_PER_EU)))
+void mlrt_render_kernel(const KParams<real> P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -757,6 +785,7 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
     // last paths of older tiles are still running, so there is no per-tile drain.  All of this state is wave-uniform.
     int t_bank = kBanks - 1, t_total = 0, t_next = 0, t_ns = 1, t_s0 = 0, t_x0 = 0, t_j = 0;
     bool queue_done = false;
+    unsigned long long st_c_trav = 0, st_c_special = 0, st_c_shade = 0, st_c0 = 0;  // MLRT_STATS: shader clocks per loop section
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
     int phase = PH_SHADE;  // every lane starts by asking for a sample
@@ -773,11 +802,19 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
     for (;;) {
         // (A) one traversal step
         pin_entry(n);
+        if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
         if (phase == PH_TRAV) {
             if (c.node < n_nodes) {
                 const int kind = n.tag & TAG_KIND_MASK;
                 if (kind == TAG_INNER) {
+#ifdef MLRT_PROBE_SLAB  // sensitivity probe (experiments only): the slab arithmetic twice, result unchanged
+                    SlabRay q = c.sr;
+                    q.of = mk(c.sr.of.y, c.sr.of.z, c.sr.of.x);
+                    const bool extra = slab_hit(n, q, (real)0.002, (real)c.closest) && c.node < 0;
+                    c.node = (slab_hit(n, c.sr, (real)0.001, (real)c.closest) || extra) ? c.node + 1 : n.link;
+#else
                     c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
+#endif
                 } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
                     double t; int aux = 0;
                     if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
@@ -790,28 +827,29 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
             }
         }
         n = fetch_entry(S, c.node, n_nodes);
-        if (P.stats) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); }
+        if (MLRT_STATS_ON(P)) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); const unsigned long long t = __builtin_readcyclecounter(); st_c_trav += t - st_c0; st_c0 = t; }
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
         if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
-            if (P.stats) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
+            if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
             if (phase == PH_SPECIAL) {
                 special_entry<FEAT>(S, n, c, o, d, g, key);
                 phase = PH_TRAV;
             }
             n = fetch_entry(S, c.node, n_nodes);
         }
+        if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_special += t - st_c0; st_c0 = t; }
         // (C) batched shading, path termination and regeneration
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
         const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
         if (batch) {
-            if (P.stats) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
+            if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
             const bool mine = phase == PH_SHADE;
             bool new_ray = false;
             bool freed = false;  // this lane flushed a bank: starved lanes may try again
             if (mine && has_path) {
-                if (P.debug_pixel >= 0 && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
+                if (MLRT_DEBUG_ON(P) && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
                     printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
                            c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
                 V3 radiance = mk(0, 0, 0);
@@ -882,7 +920,7 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    if (P.stats) { st_tiles++; st_samples += (unsigned int)t_total; }
+                    if (MLRT_STATS_ON(P)) { st_tiles++; st_samples += (unsigned int)t_total; }
                 }
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
                 const int avail = t_total - t_next;
@@ -925,13 +963,15 @@ __global__ __launch_bounds__(BLOCK) void mlrt_render_kernel(const KParams<real> 
             }
             n = fetch_entry(S, c.node, n_nodes);
         }
+        if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_shade += t - st_c0; }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
     }
-    if (P.stats && lane == 0) {
+    if (MLRT_STATS_ON(P) && lane == 0) {
         atomicAdd(&P.stats[0], (unsigned long long)st_iter); atomicAdd(&P.stats[1], (unsigned long long)st_steps);
         atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
         atomicAdd(&P.stats[4], (unsigned long long)st_hb); atomicAdd(&P.stats[5], (unsigned long long)st_hl);
         atomicAdd(&P.stats[6], (unsigned long long)st_samples); atomicAdd(&P.stats[7], (unsigned long long)st_tiles);
+        atomicAdd(&P.stats[8], st_c_trav); atomicAdd(&P.stats[9], st_c_special); atomicAdd(&P.stats[10], st_c_shade);
     }
 }
 
@@ -954,7 +994,7 @@ __global__ void mlrt_resolve_kernel(const unsigned long long* acc, int n, int sp
 // Kernel variants: FULL supports every scene; LEAN is for scenes of spheres with solid-colour materials only (the
 // `random` / `simple` worlds): 127 VGPRs instead of 168, so 1024-thread workgroups run at 4 waves per SIMD.
 #ifndef MLRT_LEAN_BLOCK
-#define MLRT_LEAN_BLOCK 1024
+#define MLRT_LEAN_BLOCK 768
 #endif
 namespace MLRT_NS {
 constexpr uint32_t kLeanFeatures = 0;
@@ -990,6 +1030,13 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
         hipLaunchKernelGGL(MLRT_NS::mlrt_resolve_kernel, dim3((unsigned)rgrid), dim3(256), 0, stream, P.acc_global, n, P.spp, P.rgb_out, P.accum_out);
     }
     return (int)hipGetLastError();
+}
+extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
+#ifdef MLRT_DEBUG_BUILD
+    return 1;
+#else
+    return 0;
+#endif
 }
 extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
 extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }

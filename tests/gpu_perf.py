@@ -24,9 +24,11 @@ def run(name, W, aspect, spp, reps=3, aperture=0.0, focus=None):
           W * H * spp / min(ms) / 1e3, r.info()), flush=True)
     if os.environ.get('MLRT_STATS'):
         import ctypes
-        st = (ctypes.c_ulonglong * 8)()
+        st = (ctypes.c_ulonglong * 16)()
         if pkg.lib().mlrt_debug_stats(r.ctx, st) == 0:
-            it, steps, sb, sl, hb, hl, samples, tiles = [int(x) for x in st]
+            it, steps, sb, sl, hb, hl, samples, tiles = [int(x) for x in st][:8]
+            ct, cs, ch = int(st[8]), int(st[9]), int(st[10])
+            print('   shader clocks per wave-iteration: trav %.0f  special %.0f (%.0f per batch)  shade %.0f (%.0f per batch); share trav %.2f special %.2f shade %.2f' % (ct / it, cs / it, cs / max(sb, 1), ch / it, ch / max(hb, 1), ct / (ct + cs + ch), cs / (ct + cs + ch), ch / (ct + cs + ch)), flush=True)
             print('   stats over %d renders: iters/sample %.2f  trav lane-steps/sample %.1f  TRAV util %.3f | special batches: %.2f lanes avg, %.2f specials/sample | shade batches: %.2f lanes avg, %.2f shades/sample' % (reps + 1, it / samples * 64 / 64, steps / samples, steps / (it * 64.0), sl / max(sb, 1), sl / samples, hl / max(hb, 1), hl / samples), flush=True)
     r.close(); w.close()
 
@@ -35,3 +37,6 @@ if __name__ == "__main__":
     if "c2" in which: run("random", 1200, 1.5, 500)
     if "c3" in which: run("random", 1200, 1.5, 500, aperture=0.1, focus=10.0)
     if "c4" in which: run("final_scene", 800, 1.0, 200)
+    if "cornell" in which: run("cornell_box", 600, 1.0, 200)
+    if "smoke" in which: run("cornell_smoke", 600, 1.0, 200)
+    if "earth" in which: run("earth", 1200, 1.5, 200)
