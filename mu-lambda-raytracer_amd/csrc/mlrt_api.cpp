@@ -435,6 +435,12 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah) {
             P.perlin_perm.push_back((uint16_t)v);
         }
     }
+    {   // sentinel: skip links that leave the array point here (index = number of real entries)
+        DNode<R> end{};
+        end.tag = TAG_END;
+        end.link = (int32_t)P.nodes.size();
+        P.nodes.push_back(end);
+    }
     P.off_nodes = append(P.blob, P.nodes);
     P.off_materials = append(P.blob, P.materials);
     P.off_textures = append(P.blob, P.textures);
@@ -638,14 +644,14 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
-            c->n_nodes = (int32_t)P.nodes.size();
+            c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
             c->block_threads = mlrt_block_threads_f32(c->variant);
         } else {
             Packed<double> P = pack<double>(*scene, false, false);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
-            c->n_nodes = (int32_t)P.nodes.size();
+            c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
             c->block_threads = mlrt_block_threads_f64(c->variant);
         }
         c->blob_bytes = (int32_t)blob.size();

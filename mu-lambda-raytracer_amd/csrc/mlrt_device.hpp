@@ -23,6 +23,7 @@ namespace mlrt {
 
 enum : int32_t {
     TAG_INNER = 0, TAG_SPHERE = 1, TAG_BOX = 2, TAG_RECT = 3, TAG_EMPTY = 4, TAG_MEDIUM = 5, TAG_XFORM = 6, TAG_XFORM_END = 7,
+    TAG_END = 8,  // the sentinel after the last entry: every walk ends on it (its index is KParams::n_nodes)
     TAG_KIND_MASK = 0xF
 };
 // TAG_RECT entries carry their axes in the tag: (a0 << 4) | (a1 << 6) | (aplane << 8)

@@ -719,9 +719,9 @@ enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  /
 // a lane's NEXT step is fetched in ONE round trip (both 16-byte halves, all lanes, clamped index) right after the cursor
 // moved, and the batch bookkeeping runs while it is in flight.  pin_entry marks where it must have arrived, which also
 // stops the compiler from sinking the loads behind the tag test (two dependent round trips per step).
-DEV DNode<real> fetch_entry(const Scene& S, int node, int n_nodes) { return S.nodes[node < n_nodes ? node : n_nodes - 1]; }
-DEV void pin_entry(DNode<real>& n) {
-    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]), "+v"(n.v[2]), "+v"(n.v[3]), "+v"(n.v[4]), "+v"(n.v[5]), "+v"(n.link), "+v"(n.tag));
+DEV DNode<real> fetch_entry(const Scene& S, int node, int n_nodes) { return S.nodes[node]; }  // node <= n_nodes: the sentinel
+DEV void pin_entry(const DNode<real>& n) {
+    asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
 // The megakernel.  Every lane runs a small state machine over its current path:
@@ -803,28 +803,33 @@ void mlrt_render_kernel(const KParams<real> P) {
         // (A) one traversal step
         pin_entry(n);
         if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
-        if (phase == PH_TRAV) {
-            if (c.node < n_nodes) {
+        // The array ends in a TAG_END sentinel, so there is no bounds test.  Two shapes of the same step (measured): the
+        // sphere-only variant runs at 6 waves per SIMD and is bound by vector-instruction issue, where two nested
+        // branches cost fewer vector instructions than selects; the full variant (4 waves, box entries resolved in the
+        // step) gains 7 % from a branch-free step.
+        if (FEAT == 0) {
+            if (phase == PH_TRAV) {
                 const int kind = n.tag & TAG_KIND_MASK;
-                if (kind == TAG_INNER) {
-#ifdef MLRT_PROBE_SLAB  // sensitivity probe (experiments only): the slab arithmetic twice, result unchanged
-                    SlabRay q = c.sr;
-                    q.of = mk(c.sr.of.y, c.sr.of.z, c.sr.of.x);
-                    const bool extra = slab_hit(n, q, (real)0.002, (real)c.closest) && c.node < 0;
-                    c.node = (slab_hit(n, c.sr, (real)0.001, (real)c.closest) || extra) ? c.node + 1 : n.link;
-#else
-                    c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
-#endif
-                } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX && !MLRT_BOX_SPECIAL) {
+                if (kind == TAG_INNER) c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
+                else phase = kind == TAG_END ? PH_SHADE : PH_SPECIAL;
+            }
+        } else {
+            const int kind = n.tag & TAG_KIND_MASK;
+            const bool trav = phase == PH_TRAV;
+            const bool inner = trav && kind == TAG_INNER;
+            const bool inside = slab_hit(n, c.sr, (real)0.001, (real)c.closest);
+            c.node = inner ? (inside ? c.node + 1 : n.link) : c.node;
+            bool handled = inner;
+            if ((FEAT & FEAT_BOX) && !MLRT_BOX_SPECIAL) {
+                const bool box = trav && kind == TAG_BOX;
+                if (box) {
                     double t; int aux = 0;
                     if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
                     c.node += 1;
-                } else {
-                    phase = PH_SPECIAL;
                 }
-            } else {
-                phase = PH_SHADE;
+                handled = handled || box;
             }
+            phase = (trav && !handled) ? (kind == TAG_END ? PH_SHADE : PH_SPECIAL) : phase;
         }
         n = fetch_entry(S, c.node, n_nodes);
         if (MLRT_STATS_ON(P)) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); const unsigned long long t = __builtin_readcyclecounter(); st_c_trav += t - st_c0; st_c0 = t; }
