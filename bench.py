@@ -159,6 +159,7 @@ def main():
                        "kernel_ms_last_launch": kernel_ms, "step_ms_hip_events": step_ms_events, **renderer.info()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
+                         "hbm_physical_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "note": "algorithmic bytes of the REFERENCE traversal (reference BVH topology, SURVEY.md 8d) per sample x samples/s: "
                                  "the scene is LDS resident and the device BVH is SAH-built, so this is not physical HBM utilisation and can exceed 1"},
         }
