@@ -539,6 +539,9 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
     K.stats = c->d_stats;
+    // per-tile primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, a pinhole camera, and few enough
+    // entries that the flat per-tile scan stays small against the tile's ~512 samples
+    K.primary_lists = (c->variant == 1 && cam->lens_radius == 0.0 && c->n_nodes <= 4096 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr) ? 1 : 0;
     K.debug_pixel = -1; K.debug_sample = -1;
     if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }
 }

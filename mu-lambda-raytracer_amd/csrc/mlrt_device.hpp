@@ -96,6 +96,7 @@ struct KParams {
     double* accum_out;    // optional [n_rows][W][3]
     unsigned int* tile_counter;
     unsigned long long* stats;  // optional [8]: iterations, trav lane-steps, special batches, special lanes, shade batches, shade lanes, samples, tiles
+    int32_t primary_lists;  // 1: sphere-only scene + pinhole camera: a tile's primary rays test a per-tile candidate list instead of walking the BVH
     int32_t debug_pixel, debug_sample;  // >= 0: printf the path of that (pixel, sample) from the kernel (MLRT_DEBUG_PIXEL=pixel,sample)
 };
 

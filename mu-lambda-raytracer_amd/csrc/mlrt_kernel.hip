@@ -68,11 +68,15 @@ constexpr int kMaxPixPerTile = 4;
 // per wave: a ring of kBanks accumulator banks (tiles in flight: the one being handed out and older ones whose last
 // paths are still running) + remaining / out_base / n_values per bank
 #ifndef MLRT_BANKS
-#define MLRT_BANKS 8
+#define MLRT_BANKS 6
 #endif
 constexpr int kBanks = MLRT_BANKS;
 constexpr int kBankValues = kMaxPixPerTile * 3;
-constexpr int kAccBytesPerWave = kBanks * kBankValues * 8 + kBanks * 12;
+// + per bank: the tile's primary candidate list (count, then up to kCand entry indices as u16; count 0xFF = not usable)
+constexpr int kCand = 14;
+constexpr int kCandInvalid = 0xFF;
+constexpr int kPrimaryFlag = 1 << 30;  // in `depth`: the lane's primary ray is working through its tile's list (index in bits 16..23)
+constexpr int kAccBytesPerWave = kBanks * kBankValues * 8 + kBanks * 12 + kBanks * 4 + kBanks * kCand * 2;
 
 // ---------------------------------------------------------------------------------------------- math helpers
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -724,6 +728,58 @@ DEV void pin_entry(const DNode<real>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
+// Primary rays of a tile (1-4 neighbouring pixels x ~125-500 samples, pinhole camera) all lie inside the pyramid from
+// the camera origin through the tile's footprint on the image plane, so they can only hit the spheres that touch
+// that pyramid: typically the ground and one or two others.  When a wave opens a tile it scans the entry array once
+// (64 entries per round, sphere against the four side planes, outward margins) and leaves the touching sphere entries,
+// in entry order, in the tile's bank; a fresh sample then tests exactly those entries instead of walking the BVH (43 %
+// of all traversal steps of `random` are primary-ray steps).  The closest hit is the one the walk finds: the walk
+// visits sphere entries in the same order, the list is a superset of the spheres any of the tile's rays can hit, and
+// Sphere::hit does not depend on what was tested before it except through closest-so-far.  Returns the count, or
+// kCandInvalid when the list does not fit (the tile's samples then walk the BVH as usual).
+DEV int build_primary_list(const KParams<real>& P, const Scene& S, int n_nodes, int x0, int npix, int j, int lane, uint16_t* list) {
+    // footprint in the (s, t) coordinates of Camera::get_ray, 1/100 pixel wider on every side
+    const double inv_w = 1.0 / ((double)P.width - 1.0), inv_h = 1.0 / ((double)P.height - 1.0);
+    const double s0 = ((double)x0 - 0.01) * inv_w, s1 = ((double)(x0 + npix) + 0.01) * inv_w;
+    const double t0 = ((double)j - 0.01) * inv_h, t1 = ((double)j + 1.01) * inv_h;
+    const P3 org = ld3p(P.cam_origin);
+    const P3 base = ld3p(P.cam_llc) - org;
+    const P3 hor = ld3p(P.cam_horizontal), ver = ld3p(P.cam_vertical);
+    auto corner = [&](double s, double t) {
+        const P3 q = base + s * hor + t * ver;
+        return mk((real)q.x, (real)q.y, (real)q.z);
+    };
+    const V3 d00 = corner(s0, t0), d10 = corner(s1, t0), d01 = corner(s0, t1), d11 = corner(s1, t1);
+    const V3 mid = d00 + d11;
+    auto plane = [&](V3 a, V3 b) {  // unit normal of the plane through the origin, a and b, pointing to the inside
+        V3 nrm = mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+        nrm = unit(nrm);
+        return dot(nrm, mid) < (real)0 ? -nrm : nrm;
+    };
+    const V3 n_left = plane(d00, d01), n_right = plane(d10, d11), n_bottom = plane(d00, d10), n_top = plane(d01, d11);
+    const V3 of = mk((real)org.x, (real)org.y, (real)org.z);
+    int count = 0;  // wave-uniform
+    for (int e0 = 0; e0 < n_nodes; e0 += 64) {
+        const int e = e0 + lane;
+        bool touches = false;
+        if (e < n_nodes) {
+            const DNode<real> q = S.nodes[e];
+            if ((q.tag & TAG_KIND_MASK) == TAG_SPHERE) {
+                const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
+                const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * (abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z));
+                touches = dot(n_left, cc) >= -reach && dot(n_right, cc) >= -reach && dot(n_bottom, cc) >= -reach && dot(n_top, cc) >= -reach;
+            }
+        }
+        const unsigned long long mask = __ballot(touches);
+        if (mask != 0ull) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+            if (touches && count + rank < kCand) list[count + rank] = (uint16_t)e;
+            count += (int)__popcll(mask);
+        }
+    }
+    return count <= kCand ? count : kCandInvalid;
+}
+
 // The megakernel.  Every lane runs a small state machine over its current path:
 //   PH_TRAV    one cheap step per loop iteration: fetch an entry, slab-test it, follow the skip link
 //   PH_SPECIAL parked on an entry that needs the long code (f64 sphere quadratic, rect, medium, transform bracket)
@@ -771,6 +827,8 @@ void mlrt_render_kernel(const KParams<real> P) {
     int* bank_remaining = reinterpret_cast<int*>(acc + kBanks * kBankValues);  // samples of the bank's tile not yet finished
     int* bank_out = bank_remaining + kBanks;                                    // first index into acc_global
     int* bank_values = bank_remaining + 2 * kBanks;                             // npix * 3
+    int* cand_count = bank_remaining + 3 * kBanks;                              // primary candidates of the bank's tile
+    uint16_t* cand = reinterpret_cast<uint16_t*>(bank_remaining + 4 * kBanks);  // [kBanks][kCand]
     const RngKey key = {P.seed_lo, P.seed_hi};
     const int spp = P.spp;
     const int n_nodes = P.n_nodes;
@@ -785,6 +843,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     // last paths of older tiles are still running, so there is no per-tile drain.  All of this state is wave-uniform.
     int t_bank = kBanks - 1, t_total = 0, t_next = 0, t_ns = 1, t_s0 = 0, t_x0 = 0, t_j = 0;
     bool queue_done = false;
+    unsigned int st_psteps = 0, st_pspecial = 0;  // MLRT_STATS: traversal steps / special entries of primary rays
     unsigned long long st_c_trav = 0, st_c_special = 0, st_c_shade = 0, st_c0 = 0;  // MLRT_STATS: shader clocks per loop section
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
@@ -802,7 +861,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     for (;;) {
         // (A) one traversal step
         pin_entry(n);
-        if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
+        if (MLRT_STATS_ON(P)) { st_c0 = __builtin_readcyclecounter(); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth)); }
         // The array ends in a TAG_END sentinel, so there is no bounds test.  Two shapes of the same step (measured): the
         // sphere-only variant runs at 6 waves per SIMD and is bound by vector-instruction issue, where two nested
         // branches cost fewer vector instructions than selects; the full variant (4 waves, box entries resolved in the
@@ -837,10 +896,16 @@ void mlrt_render_kernel(const KParams<real> P) {
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
         if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
-            if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); }
+            if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
             if (phase == PH_SPECIAL) {
                 special_entry<FEAT>(S, n, c, o, d, g, key);
                 phase = PH_TRAV;
+                if (FEAT == 0 && (depth & kPrimaryFlag)) {  // next candidate of the tile's list, or done
+                    const int k = ((depth >> 16) & 0xFF) + 1;
+                    const int bank = pix / kBankValues;
+                    if (k < cand_count[bank]) { c.node = cand[bank * kCand + k]; depth += 1 << 16; phase = PH_SPECIAL; }
+                    else { c.node = n_nodes; depth &= 0xFFFF; phase = PH_SHADE; }
+                }
             }
             n = fetch_entry(S, c.node, n_nodes);
         }
@@ -923,6 +988,10 @@ void mlrt_render_kernel(const KParams<real> P) {
                         bank_out[nb] = (row_k * P.width + t_x0) * 3;
                         bank_values[nb] = npix * 3;
                     }
+                    if (FEAT == 0 && P.primary_lists) {
+                        const int count = build_primary_list(P, S, n_nodes, t_x0, npix, t_j, lane, cand + nb * kCand);
+                        if (lane == 0) cand_count[nb] = count;
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (MLRT_STATS_ON(P)) { st_tiles++; st_samples += (unsigned int)t_total; }
@@ -961,6 +1030,14 @@ void mlrt_render_kernel(const KParams<real> P) {
                     wr.o = o; wr.d = d;
                     c.sr = slab_ray(wr);
                     phase = PH_TRAV;
+                    if (FEAT == 0 && P.primary_lists && depth == P.max_depth) {  // a fresh sample: its primary ray
+                        const int bank = pix / kBankValues;
+                        const int count = cand_count[bank];
+                        if (count != kCandInvalid) {
+                            if (count > 0) { c.node = cand[bank * kCand]; depth |= kPrimaryFlag; phase = PH_SPECIAL; }
+                            else { c.node = n_nodes; phase = PH_SHADE; }  // nothing inside the tile's frustum: background
+                        }
+                    }
                 } else if (!has_path) {
                     // no sample to be had right now: the stream is finished, or the ring is full (woken when a bank drains)
                     phase = (queue_done && t_next >= t_total) ? PH_IDLE : PH_WAIT;
@@ -976,6 +1053,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
         atomicAdd(&P.stats[4], (unsigned long long)st_hb); atomicAdd(&P.stats[5], (unsigned long long)st_hl);
         atomicAdd(&P.stats[6], (unsigned long long)st_samples); atomicAdd(&P.stats[7], (unsigned long long)st_tiles);
+        atomicAdd(&P.stats[11], (unsigned long long)st_psteps); atomicAdd(&P.stats[12], (unsigned long long)st_pspecial);
         atomicAdd(&P.stats[8], st_c_trav); atomicAdd(&P.stats[9], st_c_special); atomicAdd(&P.stats[10], st_c_shade);
     }
 }
