@@ -195,6 +195,21 @@ DEV void rng_next3(Rng& g, RngKey key, uint32_t& w0, uint32_t& w1, uint32_t& w2)
     w1 = k == 0 ? g.b1 : (k == 1 ? o2 : (k == 2 ? o3 : g.b0));
     w2 = k == 0 ? g.b2 : (k == 1 ? o3 : (k == 2 ? g.b0 : g.b1));
 }
+// The material draws of one shading batch through ONE refill site: lanes with `three` take the next three words
+// (Lambertian / Metal / Isotropic: the unit-ball sample), lanes with `one` look at the next word without consuming it
+// (Dielectric draws it only when it can refract, materials.rs:98: `cannot_refract || reflectance > rng.gen()`; the
+// caller advances the counter with rng_consume1).  Same words, same order as rng_next3 / rng_next.
+DEV void rng_material_words(Rng& g, RngKey key, bool three, bool one, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t k = g.draw & 3u;
+    const uint32_t o1 = g.b1, o2 = g.b2, o3 = g.b3;
+    const bool fill = (three && k != 1u) || (one && k == 0u);
+    if (fill) rng_fill(g, key, three ? (g.draw + 3u) >> 2 : g.draw >> 2);
+    if (three) g.draw += 3u;
+    w0 = k == 0 ? g.b0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+    w1 = k == 0 ? g.b1 : (k == 1 ? o2 : (k == 2 ? o3 : g.b0));
+    w2 = k == 0 ? g.b2 : (k == 1 ? o3 : (k == 2 ? g.b0 : g.b1));
+}
+DEV void rng_consume1(Rng& g) { g.draw++; }
 DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
 DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
 // rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
@@ -204,9 +219,7 @@ DEV real sym(uint32_t w) { return u01(w) * (real)2 + (real)-1; }  // gen_range(-
 // exactly three words - z = 2*u1 - 1, phi = 2*pi*u2, r = cbrt((w3>>8 + 1) * 2^-24) - so there is no data-dependent
 // loop: in a 37-lane shading batch the rejection loop ran ~5 times for the unluckiest lane, each time re-running
 // Philox for a handful of lanes.  Fast build: hardware sin/cos (argument in turns), log2/exp2 for the cube root.
-DEV V3 random_in_unit_sphere(Rng& g, RngKey key) {
-    uint32_t w0, w1, w2;
-    rng_next3(g, key, w0, w1, w2);
+DEV V3 unit_ball_from_words(uint32_t w0, uint32_t w1, uint32_t w2) {
     if (kFast) {
         const float z = (float)sym(w0);
         const float turn = (float)u01(w1);
@@ -620,9 +633,13 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     const DMaterial<real> m = S.materials[mat_id];
     const int mk_kind = m.kind & 0xFF;
     // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
-    // volumes.rs:79): drawn here, before the material branches, so the Philox refill runs for the whole batch at once.
+    // volumes.rs:79) and Dielectric may draw one word: fetched here, before the material branches, so ONE Philox
+    // refill site serves the whole batch.
+    const bool three = mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC);
+    uint32_t w0, w1, w2;
+    rng_material_words(g, key, three, mk_kind == MLRT_MAT_DIELECTRIC, w0, w1, w2);
     V3 s = mk(0, 0, 0);
-    if (mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC)) s = random_in_unit_sphere(g, key);
+    if (three) s = unit_ball_from_words(w0, w1, w2);
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
         if (!(dot(normal, s) > (real)0)) s = -s;  // random_in_hemisphere, vec.rs:36-43
         V3 dir = normal + s;
@@ -650,7 +667,12 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         const real sin_theta = sqrt_r((real)1 - cos_theta * cos_theta);
         const bool cannot_refract = refraction_ratio * sin_theta > (real)1;
         V3 dir;
-        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > u01(rng_next(g, key))) dir = reflect(unit_direction, normal);
+        bool reflects = cannot_refract;
+        if (!cannot_refract) {  // the draw happens only on this side of the `||` (materials.rs:98)
+            rng_consume1(g);
+            reflects = reflectance(cos_theta, refraction_ratio) > u01(w0);
+        }
+        if (reflects) dir = reflect(unit_direction, normal);
         else dir = refract(unit_direction, normal, refraction_ratio);
         o = p; d = to_p3(dir);
         return true;
