@@ -186,30 +186,19 @@ DEV uint32_t rng_next(Rng& g, RngKey key) {
     g.draw++;
     return i == 0 ? g.b0 : (i == 1 ? g.b1 : (i == 2 ? g.b2 : g.b3));
 }
-DEV void rng_next3(Rng& g, RngKey key, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    const uint32_t k = g.draw & 3u;
-    const uint32_t o1 = g.b1, o2 = g.b2, o3 = g.b3;
-    if (k != 1u) rng_fill(g, key, (g.draw + 3u) >> 2);  // k == 0: the current block; k == 2, 3: the next one
-    g.draw += 3u;
-    w0 = k == 0 ? g.b0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
-    w1 = k == 0 ? g.b1 : (k == 1 ? o2 : (k == 2 ? o3 : g.b0));
-    w2 = k == 0 ? g.b2 : (k == 1 ? o3 : (k == 2 ? g.b0 : g.b1));
+// The words of one Material::scatter.  Contract (mirrored by the oracle's PhiloxStream::begin_scatter/end_scatter): a
+// scatter starts on a block boundary and consumes its whole block, whatever the material draws from it (Lambertian /
+// Metal / Isotropic: words 0-2, the unit-ball sample; Dielectric: word 0 when it can refract, materials.rs:98).  So a
+// shading batch runs Philox exactly once, with no refill branch and no word selection; and in a scene without media
+// (whose draws happen during traversal, volumes.rs:47) the block number is just 1 + the bounce number: the stream
+// position is not per-lane state at all.
+template <uint32_t FEAT>
+DEV void rng_scatter_words(Rng& g, RngKey key, int bounce, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t block = (FEAT & FEAT_MEDIUM) ? (g.draw + 3u) >> 2 : 1u + (uint32_t)bounce;
+    uint32_t w3;
+    philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, w0, w1, w2, w3);
+    if (FEAT & FEAT_MEDIUM) g.draw = (block + 1u) << 2;
 }
-// The material draws of one shading batch through ONE refill site: lanes with `three` take the next three words
-// (Lambertian / Metal / Isotropic: the unit-ball sample), lanes with `one` look at the next word without consuming it
-// (Dielectric draws it only when it can refract, materials.rs:98: `cannot_refract || reflectance > rng.gen()`; the
-// caller advances the counter with rng_consume1).  Same words, same order as rng_next3 / rng_next.
-DEV void rng_material_words(Rng& g, RngKey key, bool three, bool one, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    const uint32_t k = g.draw & 3u;
-    const uint32_t o1 = g.b1, o2 = g.b2, o3 = g.b3;
-    const bool fill = (three && k != 1u) || (one && k == 0u);
-    if (fill) rng_fill(g, key, three ? (g.draw + 3u) >> 2 : g.draw >> 2);
-    if (three) g.draw += 3u;
-    w0 = k == 0 ? g.b0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
-    w1 = k == 0 ? g.b1 : (k == 1 ? o2 : (k == 2 ? o3 : g.b0));
-    w2 = k == 0 ? g.b2 : (k == 1 ? o3 : (k == 2 ? g.b0 : g.b1));
-}
-DEV void rng_consume1(Rng& g) { g.draw++; }
 DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
 DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
 // rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
@@ -580,7 +569,7 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
 // Evaluate the closest hit the cursor found and the material response.  Returns true when the path continues with
 // (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
 template <uint32_t FEAT>
-DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key) {
+DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key, int bounce) {
     const DNode<real> n = S.nodes[c.hit_node];
     const int kind = n.tag & TAG_KIND_MASK;
     P3 p;
@@ -633,11 +622,10 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     const DMaterial<real> m = S.materials[mat_id];
     const int mk_kind = m.kind & 0xFF;
     // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
-    // volumes.rs:79) and Dielectric may draw one word: fetched here, before the material branches, so ONE Philox
-    // refill site serves the whole batch.
+    // volumes.rs:79) and Dielectric may draw one word: the scatter's block, evaluated once for the whole batch.
     const bool three = mk_kind == MLRT_MAT_LAMBERTIAN || mk_kind == MLRT_MAT_METAL || ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC);
     uint32_t w0, w1, w2;
-    rng_material_words(g, key, three, mk_kind == MLRT_MAT_DIELECTRIC, w0, w1, w2);
+    rng_scatter_words<FEAT>(g, key, bounce, w0, w1, w2);
     V3 s = mk(0, 0, 0);
     if (three) s = unit_ball_from_words(w0, w1, w2);
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
@@ -669,7 +657,6 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         V3 dir;
         bool reflects = cannot_refract;
         if (!cannot_refract) {  // the draw happens only on this side of the `||` (materials.rs:98)
-            rng_consume1(g);
             reflects = reflectance(cos_theta, refraction_ratio) > u01(w0);
         }
         if (reflects) dir = reflect(unit_direction, normal);
@@ -948,7 +935,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                 bool done = true;
                 if (c.hit_node >= 0) {
                     V3 emitted = mk(0, 0, 0);
-                    if (shade<FEAT>(S, c, o, d, thr, emitted, g, key)) {
+                    if (shade<FEAT>(S, c, o, d, thr, emitted, g, key, P.max_depth - depth)) {
                         depth--;
                         if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
                     } else {
@@ -983,11 +970,14 @@ void mlrt_render_kernel(const KParams<real> P) {
                 const unsigned long long need = __ballot(want);
                 if (need == 0ull) break;
                 if (t_next >= t_total) {
-                    // open the next tile into the next bank of the ring, if that bank's previous tile has fully drained
-                    const int nb = (t_bank + 1) % kBanks;
+                    // open the next tile into ANY bank whose previous tile has fully drained (not the next of a ring: one
+                    // 50-bounce path would hold its bank, and with it the whole ring, while the other lanes run out of samples)
+                    if (queue_done) break;
+                    const unsigned long long free_banks = __ballot(lane < kBanks && bank_remaining[lane < kBanks ? lane : 0] == 0);
+                    if (free_banks == 0ull) break;
                     // (LDS / global loads below are wave-uniform by construction; readfirstlane tells the compiler, which
                     // keeps the tile state in scalar registers)
-                    if (queue_done || __builtin_amdgcn_readfirstlane(bank_remaining[nb]) != 0) break;
+                    const int nb = (int)__builtin_ctzll(free_banks);
                     int tile = 0;
                     if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
                     tile = __builtin_amdgcn_readfirstlane(tile);

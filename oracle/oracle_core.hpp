@@ -97,7 +97,9 @@ struct Ray {  // vec.rs:215-228
 //    (rngator.rs:27-31).  Third-party crates, sources absent from /root/reference; restated from
 //    their published algorithms and pinned by the pcg64 demo vector + SURVEY.md section 8c known answers.
 //  * PhiloxStream: Philox4x32-10 (Salmon et al., SC'11), the DEVICE's generator: one stream per
-//    (pixel, sample); draw k is 32-bit word k%4 of block k/4; uniform = (word >> 8) * 2^-24.
+//    (pixel, sample); draw k is 32-bit word k%4 of block k/4; uniform = (word >> 8) * 2^-24.  A Material::scatter
+//    starts on a block boundary and consumes its whole block (begin_scatter/end_scatter), so the device evaluates
+//    Philox exactly once per scatter with no per-lane refill logic.
 //    The HIP kernel consumes the identical words in the identical order, which makes
 //    oracle[Philox] vs GPU[Philox] comparable sample for sample.
 // ------------------------------------------------------------------------------------------------
@@ -108,6 +110,9 @@ struct Rng {
     // vec.rs:23-30 / :45-52.  The reference (and the Pcg64 mode here) draws these by rejection; the device contract
     // (PhiloxStream) draws the SAME distributions by inverse CDF from exactly 3 / 2 uniforms, see below.
     virtual bool closed_form_samplers() const { return false; }
+    // Device contract hooks around every Material::scatter call (no-ops for the reference's Pcg64 streams): see PhiloxStream.
+    virtual void begin_scatter() {}
+    virtual void end_scatter() {}
     // uniform in [0,1): the value rand 0.8.3's UniformFloat::sample_single forms before scaling.
     virtual double uniform01() = 0;
     // rand 0.8.3 UniformFloat<f64>::sample_single: value0_1 * (high-low) + low, retried if >= high.
@@ -197,6 +202,12 @@ inline void philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t
 struct PhiloxStream : Rng {
     uint32_t key[2], pixel, sample, draw;
     uint32_t buf[4];
+    uint32_t scatter_start = 0;
+    void begin_scatter() override {
+        if ((draw & 3) != 0) draw = (draw + 3u) & ~3u;  // the next draw refills
+        scatter_start = draw;
+    }
+    void end_scatter() override { draw = scatter_start + 4u; }
     PhiloxStream(uint64_t seed, uint32_t pixel_, uint32_t sample_) : pixel(pixel_), sample(sample_), draw(0) {
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
     }
@@ -873,7 +884,10 @@ inline Color trace_internal(const Ray& ray, const Hittable& world, const Backgro
     if (world.hit(ray, 0.001, INF, rng, h)) {
         Color attenuation;
         Ray scattered;
-        if (h.material->scatter(ray, h, rng, attenuation, scattered)) {
+        rng.begin_scatter();
+        const bool scatters = h.material->scatter(ray, h, rng, attenuation, scattered);
+        rng.end_scatter();
+        if (scatters) {
             g_stats.scatters++;
             return attenuation * trace_internal(scattered, world, bg, depth - 1, rng);
         }
