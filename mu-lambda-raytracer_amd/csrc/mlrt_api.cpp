@@ -26,6 +26,8 @@ uint32_t mlrt_variant_features_f64(int variant);
 int mlrt_block_threads_f32(int variant);
 int mlrt_block_threads_f64(int variant);
 int mlrt_acc_bytes_per_wave_f32(void);
+int mlrt_lds_frame_bytes_f32(void);
+int mlrt_lds_frame_bytes_f64(void);
 int mlrt_acc_bytes_per_wave_f64(void);
 int mlrt_occupancy_f32(int variant, int lds_scene, size_t dyn_lds);
 int mlrt_occupancy_f64(int variant, int lds_scene, size_t dyn_lds);
@@ -336,7 +338,7 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
 // conditions under which a medium draws (a ray that misses the boundary's box misses the boundary: volumes.rs:27-34
 // returns None before drawing).  The parity build packs the reference structure verbatim.
 template <typename R>
-Packed<R> pack(const mlrt_scene& s, bool fast, bool sah) {
+Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
     Packed<R> P;
     for (int i = 0; i < s.n_objects; i++) {
         const mlrt_object& src = s.objects[i];
@@ -416,10 +418,14 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah) {
         d.kind = m.kind | (texture_needs_uv(s, m.texture, 0) ? MATFLAG_NEEDS_UV : 0);
         d.tex = m.texture;
         for (int k = 0; k < 3; k++) d.albedo[k] = (R)m.albedo[k];
+        // a scene whose textures are all SolidColor (the LEAN kernel variant) carries the colour in the material and no
+        // texture table: 32 bytes per texture less in LDS and no dependent texture load in the shading code
+        if (solid_only && m.texture >= 0 && (m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC))
+            for (int k = 0; k < 3; k++) d.albedo[k] = (R)s.textures[m.texture].color[k];
         d.param = (R)m.param;
         P.materials.push_back(d);
     }
-    for (int i = 0; i < s.n_textures; i++) {
+    for (int i = 0; i < s.n_textures && !solid_only; i++) {
         const mlrt_texture& t = s.textures[i];
         DTexture<R> d{};
         d.kind = t.kind; d.a = t.index; d.b = t.index2;
@@ -465,6 +471,8 @@ struct mlrt_context {
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
+    uint16_t* d_cand = nullptr;  // primary candidate records, [cand_groups][16]
+    size_t cand_groups = 0;
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_acc = nullptr;  // frame accumulation buffer, grown on demand
     size_t acc_elems = 0;
@@ -486,11 +494,16 @@ void destroy(mlrt_context* c) {
     for (unsigned char* p : c->d_image_pixels) (void)hipFree(p);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_cand) (void)hipFree(c->d_cand);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
+}
+
+bool primary_lists_wanted(const mlrt_context* c, const mlrt_camera* cam, int image_height) {
+    return c->variant == 1 && cam->lens_radius == 0.0 && c->n_nodes <= 4096 && image_height < 65536 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr;
 }
 
 template <typename R>
@@ -508,40 +521,68 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
         K.bg_top[k] = (R)p->background_top[k]; K.bg_bottom[k] = (R)p->background_bottom[k];
     }
     K.lens_radius = cam->lens_radius;
+    K.has_lens = cam->lens_radius != 0.0 ? 1 : 0;
     K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
-    // Tile geometry: ~MLRT_TILE_SAMPLES samples per tile (default 512): enough to keep 64 lanes busy through the tile's
-    // ramp-up and drain, small enough that heavy-tailed tile costs (final_scene: 50-bounce paths; C2: sky vs spheres)
-    // average out over many tiles per wave - with 8000-sample tiles the waves were alive only 75 % of the kernel's
-    // duration (rocprof: sum of wave lifetimes vs wall), with 1000-sample tiles 99 %.  Low spp: several pixels per tile;
-    // high spp: a pixel's samples are split into chunks (the integer accumulation makes the split invisible).
+    // Tile geometry (see KParams).  Big chunks of ~MLRT_TILE_SAMPLES samples (default 512): enough to keep 64 lanes busy
+    // through a tile's ramp-up, with per-tile work (queue atomics, the primary candidate list) small against it.  The last
+    // samples of every pixel go out in the tapering passes of MLRT_TILE_TAIL (sizes from the END of the sample range,
+    // default "64,64,128"): the integer accumulation makes the split invisible in the image.  Low spp: several pixels per
+    // tile and a single pass.
     int target = 512;
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
-    int pix = 1, spt = p->samples_per_pixel, chunks = 1;
-    if (p->samples_per_pixel >= target) {
-        chunks = (p->samples_per_pixel + target - 1) / target;
-        spt = (p->samples_per_pixel + chunks - 1) / chunks;
-        chunks = (p->samples_per_pixel + spt - 1) / spt;
+    const int spp = p->samples_per_pixel;
+    int pix = 1;
+    K.n_big = 1; K.big = spp; K.n_tail = 0;
+    for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = spp;
+    if (spp >= 128) {
+        std::vector<int> tail;  // from the end
+        const char* spec = std::getenv("MLRT_TILE_TAIL");
+        for (const char* q = spec ? spec : "64,64,128"; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
+            const int v = std::atoi(q);
+            if (v > 0) tail.push_back(v);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        int tail_total = 0, n_tail = 0;
+        while (n_tail < (int)tail.size() && tail_total + tail[n_tail] <= spp - 64) tail_total += tail[n_tail++];  // the big passes keep >= 64 samples
+        const int rest = spp - tail_total;
+        K.n_big = (rest + target - 1) / target;
+        K.big = rest / K.n_big;  // the remainder (< n_big samples) joins the first tail pass, or is one more small pass
+        // queue order: the big passes, then tail[n_tail-1] ... tail[0]; the first pass after the big ones starts where they end
+        K.n_tail = n_tail;
+        if (n_tail == 0 && K.n_big * K.big < spp) K.n_tail = 1;
+        K.tail_s0[0] = K.n_big * K.big;
+        for (int k = 1, end = tail_total; k <= n_tail; k++) {
+            end -= tail[n_tail - k];
+            K.tail_s0[k] = spp - end;
+        }
     } else {
-        pix = std::min(4, std::max(1, (target + p->samples_per_pixel / 2) / p->samples_per_pixel));  // nearest whole number of pixels (kMaxPixPerTile)
+        pix = std::min(4, std::max(1, (target + spp / 2) / spp));  // nearest whole number of pixels (kMaxPixPerTile)
         pix = std::min(pix, (int)p->image_width);
     }
     K.pix_per_tile = pix;
     K.tiles_per_row = (p->image_width + pix - 1) / pix;
-    K.spp_per_tile = spt;
-    K.chunks = chunks;
-    const int64_t n_tiles64 = (int64_t)K.tiles_per_row * n_rows * chunks;
+    K.n_groups = K.tiles_per_row * n_rows;
+    const int64_t n_tiles64 = (int64_t)K.n_groups * (K.n_big + K.n_tail);
     MLRT_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
     K.n_tiles = (int32_t)n_tiles64;
+    {   // cut the wave's accumulator area (mlrt_kernel.hip kAccBytesPerWave) into banks: sums + remaining/out/values + candidate list
+        const int area = c->precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64();
+        K.bank_values = 3 * pix;
+        K.n_banks = std::max(1, std::min(16, (area - 16 * (12 + 32)) / (K.bank_values * 8)));  // kMaxBanks x (3 ints + candidate record)
+    }
     K.acc_global = c->d_acc;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
+    K.n_queues = 8;
+    if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) { const int v = std::atoi(nq); if (v >= 1 && v <= mlrt::kMaxQueues && (v & (v - 1)) == 0) K.n_queues = v; }
     K.stats = c->d_stats;
-    // per-tile primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, a pinhole camera, and few enough
-    // entries that the flat per-tile scan stays small against the tile's ~512 samples
-    K.primary_lists = (c->variant == 1 && cam->lens_radius == 0.0 && c->n_nodes <= 4096 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr) ? 1 : 0;
+    // per-pixel-group primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, a pinhole camera, and few
+    // enough entries that the pre-pass's flat scan stays small against the frame
+    K.primary_lists = primary_lists_wanted(c, cam, p->image_height) ? c->d_cand : nullptr;
     K.debug_pixel = -1; K.debug_sample = -1;
     if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }
 }
@@ -569,8 +610,18 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
         MLRT_HIP(hipMalloc(&c->d_acc, need * sizeof(unsigned long long)));
         c->acc_elems = need;
     }
+    if (primary_lists_wanted(c, cam, p->image_height)) {  // one 32-byte record per pixel group; at most one group per pixel
+        const size_t groups = (size_t)n_rows * (size_t)p->image_width;
+        if (groups > c->cand_groups) {
+            MLRT_HIP(hipStreamSynchronize(stream));
+            if (c->d_cand) MLRT_HIP(hipFree(c->d_cand));
+            c->d_cand = nullptr; c->cand_groups = 0;
+            MLRT_HIP(hipMalloc(&c->d_cand, groups * 32));
+            c->cand_groups = groups;
+        }
+    }
     MLRT_HIP(hipMemsetAsync(c->d_acc, 0, need * sizeof(unsigned long long), stream));
-    MLRT_HIP(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), stream));
+    MLRT_HIP(hipMemsetAsync(c->d_tile_counter, 0, mlrt::kMaxQueues * 64, stream));
     const int waves_per_block = c->block_threads / 64;
     int rc;
     int grid;
@@ -642,15 +693,16 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         const uint32_t lean = precision == MLRT_PRECISION_FP32 ? mlrt_variant_features_f32(1) : mlrt_variant_features_f64(1);
         c->variant = ((c->features & ~lean) == 0 && std::getenv("MLRT_FORCE_FULL") == nullptr) ? 1 : 0;
         std::vector<unsigned char> blob;
+        const bool solid_only = c->variant == 1;  // the LEAN kernel variant reads no texture table (its scenes have SolidColor textures only)
         if (precision == MLRT_PRECISION_FP32) {
-            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr, std::getenv("MLRT_NO_SAH") == nullptr);
+            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr, std::getenv("MLRT_NO_SAH") == nullptr, solid_only);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
             c->block_threads = mlrt_block_threads_f32(c->variant);
         } else {
-            Packed<double> P = pack<double>(*scene, false, false);
+            Packed<double> P = pack<double>(*scene, false, false, solid_only);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
@@ -673,7 +725,7 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             MLRT_HIP(hipMalloc(&c->d_images, images.size() * sizeof(DImage)));
             MLRT_HIP(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DImage), hipMemcpyHostToDevice));
         }
-        MLRT_HIP(hipMalloc(&c->d_tile_counter, sizeof(unsigned int)));
+        MLRT_HIP(hipMalloc(&c->d_tile_counter, mlrt::kMaxQueues * 64));
         if (std::getenv("MLRT_STATS") || std::getenv("MLRT_DEBUG_PIXEL")) {
             const bool instrumented = (precision == MLRT_PRECISION_FP64 ? mlrt_instrumented_f64() : mlrt_instrumented_f32()) != 0;
             if (!instrumented) std::fprintf(stderr, "mlrt: MLRT_STATS / MLRT_DEBUG_PIXEL need the debug build of the library (python mu-lambda-raytracer_amd/build.py --debug; MLRT_LIB=.../libmlrt_hip_debug.so): ignored\n");
@@ -683,7 +735,8 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
         MLRT_HIP(hipEventCreate(&c->ev_stop));
         // LDS plan: the f32 blob is staged in LDS when it fits next to the per-wave accumulators
         const int waves = c->block_threads / 64;
-        const size_t acc = (size_t)waves * (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64());
+        const size_t acc = (size_t)waves * (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64())
+                           + (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_lds_frame_bytes_f32() : mlrt_lds_frame_bytes_f64());  // + the frame parameters
         const size_t lds_limit = 160 * 1024;
         c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit && std::getenv("MLRT_NO_LDS") == nullptr;
         c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;

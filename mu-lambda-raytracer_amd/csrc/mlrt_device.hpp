@@ -74,6 +74,9 @@ struct DImage {
     int32_t width, height;
 };
 
+constexpr int kMaxTailPasses = 8;
+constexpr int kMaxQueues = 64;
+
 template <typename R>
 struct KParams {
     const unsigned char* blob;  // packed scene in HBM
@@ -83,20 +86,29 @@ struct KParams {
     const DImage* images;
     // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
-    double lens_radius;
+    double lens_radius;  // (cam_origin ... lens_radius stay contiguous: the kernel copies them as 19 doubles)
+    int32_t has_lens;    // lens_radius != 0
     int32_t width, height, spp, max_depth;
     uint32_t seed_lo, seed_hi;
     int32_t bg_kind;
     R bg_top[3], bg_bottom[3];
-    // work decomposition: a tile = pix_per_tile consecutive pixels of one row x one chunk of spp_per_tile samples
+    // Work decomposition: a tile = one pixel group (pix_per_tile consecutive pixels of one row) x one chunk of its
+    // samples.  The queue is chunk-major - pass p hands out chunk p of EVERY pixel group before pass p + 1 starts - and
+    // the chunks taper: n_big passes of `big` samples, then the passes of tail_s0 (sample offsets; tail_s0[n_tail] = spp),
+    // shrinking to one path per lane.  Tile costs are heavy-tailed (one 500-sample tile on a glass sphere of `random`
+    // takes 2.8 ms, the average 0.05 ms), so the launch must END on small tiles: its tail is the longest tile taken late.
     const int32_t* rows;  // device array of row indices or nullptr (= identity)
-    int32_t n_rows, pix_per_tile, tiles_per_row, spp_per_tile, chunks, n_tiles;
+    int32_t n_rows, pix_per_tile, tiles_per_row, n_groups, n_big, big, n_tail, n_tiles;
+    int32_t tail_s0[kMaxTailPasses + 1];
+    int32_t n_banks, bank_values;  // the wave's LDS accumulator area: n_banks banks of bank_values (= 3 * pix_per_tile) sums
     unsigned long long* acc_global;  // [n_rows][W][3] 2^-32 fixed-point colour sums (integer adds: order independent)
     int32_t* rgb_out;     // [n_rows][W][3], written by the resolve kernel
     double* accum_out;    // optional [n_rows][W][3]
-    unsigned int* tile_counter;
+    unsigned int* tile_counter;  // [n_queues] counters, 64 bytes apart
+    int32_t n_queues;            // power of two <= kMaxQueues
     unsigned long long* stats;  // optional [8]: iterations, trav lane-steps, special batches, special lanes, shade batches, shade lanes, samples, tiles
-    int32_t primary_lists;  // 1: sphere-only scene + pinhole camera: a tile's primary rays test a per-tile candidate list instead of walking the BVH
+    const uint16_t* primary_lists;  // or nullptr; sphere-only scene + pinhole camera: [n_groups][16] per-pixel-group candidate records (mlrt_primary_lists_kernel):
+                                    // a group's primary rays test those entries instead of walking the BVH
     int32_t debug_pixel, debug_sample;  // >= 0: printf the path of that (pixel, sample) from the kernel (MLRT_DEBUG_PIXEL=pixel,sample)
 };
 

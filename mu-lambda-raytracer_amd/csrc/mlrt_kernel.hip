@@ -40,6 +40,10 @@
 #define MLRT_BLOCK 512
 #endif
 #define DEV __device__ __forceinline__
+// Branch weights for the register allocator: the traversal step runs every iteration of the kernel loop, the batches every
+// ~10th, a tile is opened every ~500th.  Without them a value the step reads (the slab ray) is as good a spill candidate
+// as one only the shading code reads, and at 80 registers the difference is 2x in frame time.
+#define MLRT_RARELY(x) __builtin_expect(!!(x), 0)
 // Instrumentation (in-kernel counters MLRT_STATS=1, the per-sample path printer MLRT_DEBUG_PIXEL=p,s) exists only in the
 // debug build of the library (build.py --debug -> libmlrt_hip_debug.so).  Even switched off at run time it costs the
 // render kernel 8 %: its wave-uniform counters and the printf call's registers push tile and camera state out of the
@@ -64,19 +68,29 @@ using namespace mlrt;
 
 typedef MLRT_REAL real;
 constexpr bool kFast = sizeof(real) == 4;
-constexpr int kMaxPixPerTile = 4;
-// per wave: a ring of kBanks accumulator banks (tiles in flight: the one being handed out and older ones whose last
-// paths are still running) + remaining / out_base / n_values per bank
-#ifndef MLRT_BANKS
-#define MLRT_BANKS 6
-#endif
-constexpr int kBanks = MLRT_BANKS;
-constexpr int kBankValues = kMaxPixPerTile * 3;
+// Per wave: kAccBytesPerWave bytes of LDS holding the accumulator banks, one per tile in flight (the one being handed out
+// and older ones whose last paths are still running): [remaining | out | values][kMaxBanks] ints, the
+// candidate records, then the sums - n_banks x bank_values of them, cut at run time (KParams): one-pixel tiles get all 16
+// banks, four-pixel tiles 6.  Many banks matter with small tiles: one 50-bounce path holds its bank while the other
+// lanes finish ~8 tiles' worth of 64-sample tiles.
+constexpr int kAccBytesPerWave = 1344;
+constexpr int kMaxBanks = 16;
 // + per bank: the tile's primary candidate list (count, then up to kCand entry indices as u16; count 0xFF = not usable)
 constexpr int kCand = 14;
 constexpr int kCandInvalid = 0xFF;
 constexpr int kPrimaryFlag = 1 << 30;  // in `depth`: the lane's primary ray is working through its tile's list (index in bits 16..23)
-constexpr int kAccBytesPerWave = kBanks * kBankValues * 8 + kBanks * 12 + kBanks * 4 + kBanks * kCand * 2;
+constexpr int kPixBankShift = 10;      // `pix` = bank << 10 | index of the pixel's first sum in the wave's acc array
+
+// Per-frame parameters only the sample generation and the path ends read (camera.rs:3-12, the background): every
+// workgroup copies them from the kernel arguments into LDS once.  Left in the argument struct they sit in ~50 scalar
+// registers for the whole kernel (the compiler hoists the loads), which spilled scalar registers into vector lanes.
+struct FrameParams {
+    double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
+    double lens_radius;
+    MLRT_REAL bg_top[3], bg_bottom[3];
+};
+constexpr int kFrameParamBytes = 208;
+static_assert(sizeof(FrameParams) <= kFrameParamBytes, "FrameParams must fit its LDS slot");
 
 // ---------------------------------------------------------------------------------------------- math helpers
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -510,8 +524,10 @@ DEV real perlin_turbulence(const Scene& S, int table, V3 p) {  // textures.rs:76
     }
     return abs_r(accum);
 }
+// A scene of SolidColor textures only has the colour in the material (`solid`) and no texture table (mlrt_api.cpp pack).
 template <uint32_t FEAT>
-DEV V3 texture_value(const Scene& S, int tex, real u, real v, V3 p) {
+DEV V3 texture_value(const Scene& S, int tex, V3 solid, real u, real v, V3 p) {
+    if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_NOISE | FEAT_TEX_CHECKER)) == 0) return solid;
     DTexture<real> t = S.textures[tex];
     for (int guard = 0; (FEAT & FEAT_TEX_CHECKER) && guard < 8 && t.kind == MLRT_TEX_CHECKER; guard++) {  // textures.rs:40-49
         const real sines = sin_r((real)5 * p.x) * sin_r((real)5 * p.y) * sin_r((real)5 * p.z);
@@ -633,7 +649,7 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         V3 dir = normal + s;
         const real eps = (real)1e-8;
         if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
-        thr = thr * texture_value<FEAT>(S, m.tex, u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);
         o = p; d = to_p3(dir);
         return true;
     }
@@ -666,19 +682,19 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     }
     if ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
         const V3 dir = s;
-        thr = thr * texture_value<FEAT>(S, m.tex, u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);
         o = p; d = to_p3(dir);
         return true;
     }
-    emitted = texture_value<FEAT>(S, m.tex, u, v, pf);  // DiffuseLight, materials.rs:119-127
+    emitted = texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);  // DiffuseLight, materials.rs:119-127
     return false;
 }
 
-DEV V3 background_color(const KParams<real>& P, P3 d) {  // raytrace.rs:29-35, 44-48
+DEV V3 background_color(const KParams<real>& P, const FrameParams& F, P3 d) {  // raytrace.rs:29-35, 44-48
     if (P.bg_kind == MLRT_BG_BLACK) return mk(0, 0, 0);
     const V3 ud = unit(to_v3(d));
     const real t = (real)0.5 * (ud.y + (real)1);
-    return ((real)1 - t) * ld3(P.bg_bottom) + t * ld3(P.bg_top);
+    return ((real)1 - t) * ld3(F.bg_bottom) + t * ld3(F.bg_top);
 }
 
 // raytrace.rs:191-193 + Camera::get_ray, camera.rs:40-48, in f64 in both builds: the uniforms are 24-bit values
@@ -686,26 +702,26 @@ DEV V3 background_color(const KParams<real>& P, P3 d) {  // raytrace.rs:29-35, 4
 // evaluates the lens offset's sin/cos in f32).  A fresh sample's four draws - u, v and the lens sample, drawn by
 // inverse CDF from two words (r = sqrt(u1'), phi = 2*pi*u2; the reference's rejection loop is vec.rs:45-52, quirk Q6:
 // the draws are consumed even when lens_radius == 0) - are exactly Philox block 0: no loop, no refill branch.
-DEV void gen_camera_ray(const KParams<real>& P, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
+DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
     rng_fill(g, key, 0u);
     g.draw = 4u;
     const double s = ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
     const double t = ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
     double rdx = 0.0, rdy = 0.0;
-    if (P.lens_radius != 0.0) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
+    if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
         const double u1 = ((double)(g.b2 >> 8) + 1.0) * (1.0 / 16777216.0);
         const double turn = u01d(g.b3);
         double cs, sn;
         if (kFast) { cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
         else { const double phi = 2.0 * 3.14159265358979323846264338327950288 * turn; cs = cos(phi); sn = sin(phi); }
         const double r = sqrt(u1);
-        rdx = P.lens_radius * (r * cs);
-        rdy = P.lens_radius * (r * sn);
+        rdx = F.lens_radius * (r * cs);
+        rdy = F.lens_radius * (r * sn);
     }
-    const P3 offset = ld3p(P.cam_u) * rdx + ld3p(P.cam_v) * rdy;
-    const P3 origin = ld3p(P.cam_origin);
+    const P3 offset = ld3p(F.cam_u) * rdx + ld3p(F.cam_v) * rdy;
+    const P3 origin = ld3p(F.cam_origin);
     o = origin + offset;
-    d = ld3p(P.cam_llc) + s * ld3p(P.cam_horizontal) + t * ld3p(P.cam_vertical) - origin - offset;
+    d = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin - offset;
 }
 
 // 2^-32 fixed point; integer accumulation is order independent (within a tile in LDS, across tiles in HBM).  NaN/negative radiance cannot occur on this
@@ -737,16 +753,25 @@ DEV void pin_entry(const DNode<real>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
-// Primary rays of a tile (1-4 neighbouring pixels x ~125-500 samples, pinhole camera) all lie inside the pyramid from
-// the camera origin through the tile's footprint on the image plane, so they can only hit the spheres that touch
-// that pyramid: typically the ground and one or two others.  When a wave opens a tile it scans the entry array once
-// (64 entries per round, sphere against the four side planes, outward margins) and leaves the touching sphere entries,
-// in entry order, in the tile's bank; a fresh sample then tests exactly those entries instead of walking the BVH (43 %
-// of all traversal steps of `random` are primary-ray steps).  The closest hit is the one the walk finds: the walk
-// visits sphere entries in the same order, the list is a superset of the spheres any of the tile's rays can hit, and
-// Sphere::hit does not depend on what was tested before it except through closest-so-far.  Returns the count, or
-// kCandInvalid when the list does not fit (the tile's samples then walk the BVH as usual).
-DEV int build_primary_list(const KParams<real>& P, const Scene& S, int n_nodes, int x0, int npix, int j, int lane, uint16_t* list) {
+// Primary rays of a pixel group (1-4 neighbouring pixels, pinhole camera) all lie inside the pyramid from the camera
+// origin through the group's footprint on the image plane, so they can only hit the spheres that touch that pyramid:
+// typically the ground and one or two others.  A pre-pass (one thread per pixel group, once per frame) scans the entry
+// array (sphere against the four side planes, outward margins) and leaves the touching sphere entries, in entry order,
+// in a 32-byte record: u16 count (kCandInvalid when more than kCand touch: that group's samples walk the BVH as usual),
+// the entry indices, and the group's image row.  A wave opening a tile copies the record into the tile's bank, and a fresh sample tests
+// exactly those entries instead of walking the BVH (43 % of all traversal steps of `random` are primary-ray steps).
+// The closest hit is the one the walk finds: the walk visits sphere entries in the same order, the list is a superset
+// of the spheres any of the group's rays can hit, and Sphere::hit does not depend on what was tested before it except
+// through closest-so-far.
+constexpr int kCandRecord = 16;  // u16 per record: count + kCand entries + pad
+__global__ void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* records) {
+    const int group = blockIdx.x * blockDim.x + threadIdx.x;
+    if (group >= P.n_groups) return;
+    const DNode<real>* nodes = reinterpret_cast<const DNode<real>*>(P.blob + P.off_nodes);
+    const int row_k = group / P.tiles_per_row;
+    const int x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
+    const int npix = min(P.pix_per_tile, P.width - x0);
+    const int j = P.rows ? P.rows[row_k] : row_k;
     // footprint in the (s, t) coordinates of Camera::get_ray, 1/100 pixel wider on every side
     const double inv_w = 1.0 / ((double)P.width - 1.0), inv_h = 1.0 / ((double)P.height - 1.0);
     const double s0 = ((double)x0 - 0.01) * inv_w, s1 = ((double)(x0 + npix) + 0.01) * inv_w;
@@ -767,26 +792,26 @@ DEV int build_primary_list(const KParams<real>& P, const Scene& S, int n_nodes, 
     };
     const V3 n_left = plane(d00, d01), n_right = plane(d10, d11), n_bottom = plane(d00, d10), n_top = plane(d01, d11);
     const V3 of = mk((real)org.x, (real)org.y, (real)org.z);
-    int count = 0;  // wave-uniform
-    for (int e0 = 0; e0 < n_nodes; e0 += 64) {
-        const int e = e0 + lane;
-        bool touches = false;
-        if (e < n_nodes) {
-            const DNode<real> q = S.nodes[e];
-            if ((q.tag & TAG_KIND_MASK) == TAG_SPHERE) {
-                const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
-                const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * (abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z));
-                touches = dot(n_left, cc) >= -reach && dot(n_right, cc) >= -reach && dot(n_bottom, cc) >= -reach && dot(n_top, cc) >= -reach;
-            }
-        }
-        const unsigned long long mask = __ballot(touches);
-        if (mask != 0ull) {
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-            if (touches && count + rank < kCand) list[count + rank] = (uint16_t)e;
-            count += (int)__popcll(mask);
+    uint16_t list[kCandRecord];
+#pragma unroll
+    for (int k = 0; k < kCandRecord; k++) list[k] = 0;
+    int count = 0;
+    for (int e = 0; e < P.n_nodes; e++) {  // e is uniform: the entry is read once per wave
+        const DNode<real> q = nodes[e];
+        if ((q.tag & TAG_KIND_MASK) != TAG_SPHERE) continue;
+        const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
+        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * (abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z));
+        if (dot(n_left, cc) >= -reach && dot(n_right, cc) >= -reach && dot(n_bottom, cc) >= -reach && dot(n_top, cc) >= -reach) {
+#pragma unroll
+            for (int k = 0; k < kCand; k++) if (k == count) list[1 + k] = (uint16_t)e;
+            count++;
         }
     }
-    return count <= kCand ? count : kCandInvalid;
+    list[0] = (uint16_t)(count <= kCand ? count : kCandInvalid);
+    list[kCandRecord - 1] = (uint16_t)j;  // the group's image row rides along (image height < 65536)
+    uint32_t* out = reinterpret_cast<uint32_t*>(records + (size_t)group * kCandRecord);
+#pragma unroll
+    for (int k = 0; k < kCandRecord / 2; k++) out[k] = (uint32_t)list[2 * k] | ((uint32_t)list[2 * k + 1] << 16);
 }
 
 // The megakernel.  Every lane runs a small state machine over its current path:
@@ -807,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0
 void mlrt_render_kernel(const KParams<real> P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the wave's LDS addresses are SGPR + immediate
 
     const unsigned char* base;
     unsigned char* acc_base;
@@ -817,13 +842,16 @@ void mlrt_render_kernel(const KParams<real> P) {
         uint4* dst = reinterpret_cast<uint4*>(smem);
         const int n16 = P.blob_bytes >> 4;
         for (int i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
-        __syncthreads();
         base = smem;
         acc_base = smem + P.blob_bytes;
     } else {
         base = P.blob;
         acc_base = smem;
     }
+    FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytesPerWave);
+    if (threadIdx.x < 19) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... lens_radius are contiguous in both structs
+    if (threadIdx.x < 3) { F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x]; }
+    __syncthreads();
     Scene S;
     S.nodes = reinterpret_cast<const DNode<real>*>(base + P.off_nodes);
     S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
@@ -832,17 +860,16 @@ void mlrt_render_kernel(const KParams<real> P) {
     S.perlin_perm = reinterpret_cast<const uint16_t*>(base + P.off_perlin_perm);
     S.images = P.images;
 
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_base + wave * kAccBytesPerWave);  // [kBanks][kBankValues]
-    int* bank_remaining = reinterpret_cast<int*>(acc + kBanks * kBankValues);  // samples of the bank's tile not yet finished
-    int* bank_out = bank_remaining + kBanks;                                    // first index into acc_global
-    int* bank_values = bank_remaining + 2 * kBanks;                             // npix * 3
-    int* cand_count = bank_remaining + 3 * kBanks;                              // primary candidates of the bank's tile
-    uint16_t* cand = reinterpret_cast<uint16_t*>(bank_remaining + 4 * kBanks);  // [kBanks][kCand]
+    const int n_banks = P.n_banks, bank_vals = P.bank_values;  // wave-uniform
+    int* bank_remaining = reinterpret_cast<int*>(acc_base + wave * kAccBytesPerWave);  // samples of the bank's tile not yet finished
+    int* bank_out = bank_remaining + kMaxBanks;                                         // first index into acc_global
+    int* bank_values = bank_remaining + 2 * kMaxBanks;                                  // npix * 3
+    uint16_t* cand = reinterpret_cast<uint16_t*>(bank_remaining + 3 * kMaxBanks);       // [kMaxBanks][kCandRecord]: the tile's primary candidates
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(cand + kMaxBanks * kCandRecord);  // [n_banks][bank_vals]
     const RngKey key = {P.seed_lo, P.seed_hi};
-    const int spp = P.spp;
     const int n_nodes = P.n_nodes;
 
-    if (lane < kBanks) bank_remaining[lane] = 0;
+    if (lane < n_banks) bank_remaining[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -850,15 +877,31 @@ void mlrt_render_kernel(const KParams<real> P) {
     // the global queue; its pixels*samples form a queue handed out to lanes in order.  Tiles OVERLAP: when the current
     // tile's queue is exhausted the next one is opened at once (into the next accumulator bank of the ring) while the
     // last paths of older tiles are still running, so there is no per-tile drain.  All of this state is wave-uniform.
-    int t_bank = kBanks - 1, t_total = 0, t_next = 0, t_ns = 1, t_s0 = 0, t_x0 = 0, t_j = 0;
+    int t_bank = 0, t_total = 0, t_next = 0, t_ns = 1, t_s0 = 0, t_x0 = 0, t_j = 0;
     bool queue_done = false;
+    // The queue is n_queues interleaved sub-queues (sub-queue k holds tiles k, k + n_queues, ...), each with its own
+    // counter on its own cache line: with ONE counter for all waves of the GPU and 64-sample tiles the tail passes ran at
+    // the rate of same-address device-scope atomics (one every ~13 ns was needed).  A wave starts on the sub-queue of its
+    // workgroup and moves on when that one is exhausted.
+    int q_id = (int)blockIdx.x & (P.n_queues - 1), q_tried = 0;  // the wave's sub-queue; sub-queues found exhausted
+    const bool lists = FEAT == 0 && P.primary_lists != nullptr;
+    auto queue_pop = [&]() -> int {  // synchronous; n_tiles when every sub-queue is exhausted
+        for (;;) {
+            int i = 0;
+            if (lane == 0) i = (int)atomicAdd(P.tile_counter + q_id * 16, 1u);
+            const int t = __builtin_amdgcn_readfirstlane(i) * P.n_queues + q_id;
+            if (t < P.n_tiles) return t;
+            if (++q_tried >= P.n_queues) return P.n_tiles;
+            q_id = (q_id + 1) & (P.n_queues - 1);
+        }
+    };
     unsigned int st_psteps = 0, st_pspecial = 0;  // MLRT_STATS: traversal steps / special entries of primary rays
     unsigned long long st_c_trav = 0, st_c_special = 0, st_c_shade = 0, st_c0 = 0;  // MLRT_STATS: shader clocks per loop section
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
     int phase = PH_SHADE;  // every lane starts by asking for a sample
     bool has_path = false;
-    int pix = 0, depth = 0;  // pix: value index base of the lane's pixel inside its bank (bank * kBankValues + pixel * 3)
+    int pix = 0, depth = 0;  // pix: the lane's bank << kPixBankShift | index of its pixel's first sum in acc
     P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
     V3 thr = mk(1, 1, 1);
     Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -904,15 +947,15 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
-        if (m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull)) {
+        if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull))) {
             if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
             if (phase == PH_SPECIAL) {
                 special_entry<FEAT>(S, n, c, o, d, g, key);
                 phase = PH_TRAV;
                 if (FEAT == 0 && (depth & kPrimaryFlag)) {  // next candidate of the tile's list, or done
                     const int k = ((depth >> 16) & 0xFF) + 1;
-                    const int bank = pix / kBankValues;
-                    if (k < cand_count[bank]) { c.node = cand[bank * kCand + k]; depth += 1 << 16; phase = PH_SPECIAL; }
+                    const int bank = pix >> kPixBankShift;
+                    if (k < cand[bank * kCandRecord]) { c.node = cand[bank * kCandRecord + 1 + k]; depth += 1 << 16; phase = PH_SPECIAL; }
                     else { c.node = n_nodes; depth &= 0xFFFF; phase = PH_SHADE; }
                 }
             }
@@ -922,7 +965,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         // (C) batched shading, path termination and regeneration
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
         const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
-        if (batch) {
+        if (MLRT_RARELY(batch)) {
             if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
             const bool mine = phase == PH_SHADE;
             bool new_ray = false;
@@ -942,22 +985,23 @@ void mlrt_render_kernel(const KParams<real> P) {
                         radiance = thr * emitted;
                     }
                 } else {
-                    radiance = thr * background_color(P, d);
+                    radiance = thr * background_color(P, F, d);
                 }
                 if (done) {
-                    atomicAdd(&acc[pix + 0], to_fixed(radiance.x));
-                    atomicAdd(&acc[pix + 1], to_fixed(radiance.y));
-                    atomicAdd(&acc[pix + 2], to_fixed(radiance.z));
+                    const int sum0 = pix & ((1 << kPixBankShift) - 1);
+                    atomicAdd(&acc[sum0 + 0], to_fixed(radiance.x));
+                    atomicAdd(&acc[sum0 + 1], to_fixed(radiance.y));
+                    atomicAdd(&acc[sum0 + 2], to_fixed(radiance.z));
                     has_path = false;
                     // the lane that finishes the last sample of a tile flushes that tile's sums into the frame buffer:
                     // integer atomics, so the frame is bit-identical however pixels' samples were split into tiles and
                     // whichever wave / GPU rendered them (LDS operations of a wave execute in order, so every add of
                     // the tile is visible to the lane that sees the count reach zero)
-                    const int bank = pix / kBankValues;
+                    const int bank = pix >> kPixBankShift;
                     if (atomicSub(&bank_remaining[bank], 1) == 1) {
                         const int n_values = bank_values[bank];
                         const int out0 = bank_out[bank];
-                        for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * kBankValues + i]);
+                        for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * bank_vals + i]);
                         freed = true;
                     }
                 }
@@ -969,41 +1013,44 @@ void mlrt_render_kernel(const KParams<real> P) {
             for (;;) {
                 const unsigned long long need = __ballot(want);
                 if (need == 0ull) break;
-                if (t_next >= t_total) {
+                if (MLRT_RARELY(t_next >= t_total)) {
                     // open the next tile into ANY bank whose previous tile has fully drained (not the next of a ring: one
                     // 50-bounce path would hold its bank, and with it the whole ring, while the other lanes run out of samples)
                     if (queue_done) break;
-                    const unsigned long long free_banks = __ballot(lane < kBanks && bank_remaining[lane < kBanks ? lane : 0] == 0);
+                    const unsigned long long free_banks = __ballot(lane < n_banks && bank_remaining[lane < n_banks ? lane : 0] == 0);
                     if (free_banks == 0ull) break;
                     // (LDS / global loads below are wave-uniform by construction; readfirstlane tells the compiler, which
                     // keeps the tile state in scalar registers)
                     const int nb = (int)__builtin_ctzll(free_banks);
-                    int tile = 0;
-                    if (lane == 0) tile = (int)atomicAdd(P.tile_counter, 1u);
-                    tile = __builtin_amdgcn_readfirstlane(tile);
+                    const int tile = queue_pop();
                     if (tile >= P.n_tiles) { queue_done = true; break; }
-                    // tile -> (row, pixel group, sample chunk); chunks of one pixel group are adjacent in the queue
-                    const int group = tile / P.chunks;
-                    const int chunk = tile - group * P.chunks;
+                    // tile -> (pass, pixel group): chunk-major queue, see KParams
+                    const int pass = tile / P.n_groups;
+                    const int group = tile - pass * P.n_groups;
                     const int row_k = group / P.tiles_per_row;
                     t_x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
                     const int npix = min(P.pix_per_tile, P.width - t_x0);
-                    t_s0 = chunk * P.spp_per_tile;
-                    t_ns = min(P.spp_per_tile, spp - t_s0);  // samples of every pixel handled by this tile
-                    t_j = P.rows ? __builtin_amdgcn_readfirstlane(P.rows[row_k]) : row_k;
+                    if (pass < P.n_big) {
+                        t_s0 = pass * P.big;
+                        t_ns = P.big;
+                    } else {
+                        t_s0 = P.tail_s0[pass - P.n_big];
+                        t_ns = P.tail_s0[pass - P.n_big + 1] - t_s0;  // samples of every pixel handled by this tile
+                    }
+                    uint32_t rec = 0u;  // lanes 0-7: the group's record (pre-pass), with its image row in the last half word
+                    if (lists) { if (lane < kCandRecord / 2) rec = reinterpret_cast<const uint32_t*>(P.primary_lists + (size_t)group * kCandRecord)[lane]; }
+                    else if (P.rows) rec = (uint32_t)P.rows[row_k];
+                    t_j = lists ? (int)(__builtin_amdgcn_readlane(rec, kCandRecord / 2 - 1) >> 16) : (P.rows ? (int)__builtin_amdgcn_readfirstlane(rec) : row_k);
                     t_total = npix * t_ns;
                     t_next = 0;
                     t_bank = nb;
-                    if (lane < npix * 3) acc[nb * kBankValues + lane] = 0ull;
+                    if (lane < npix * 3) acc[nb * bank_vals + lane] = 0ull;
                     if (lane == 0) {
                         bank_remaining[nb] = t_total;
                         bank_out[nb] = (row_k * P.width + t_x0) * 3;
                         bank_values[nb] = npix * 3;
                     }
-                    if (FEAT == 0 && P.primary_lists) {
-                        const int count = build_primary_list(P, S, n_nodes, t_x0, npix, t_j, lane, cand + nb * kCand);
-                        if (lane == 0) cand_count[nb] = count;
-                    }
+                    if (lists && lane < kCandRecord / 2) reinterpret_cast<uint32_t*>(cand + nb * kCandRecord)[lane] = rec;  // the group's record (pre-pass)
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (MLRT_STATS_ON(P)) { st_tiles++; st_samples += (unsigned int)t_total; }
@@ -1014,10 +1061,10 @@ void mlrt_render_kernel(const KParams<real> P) {
                     const int q = t_next + rank;
                     const int p_in_tile = q / t_ns;
                     const int smp = t_s0 + (q - p_in_tile * t_ns);
-                    pix = t_bank * kBankValues + p_in_tile * 3;
+                    pix = (t_bank << kPixBankShift) | (t_bank * bank_vals + p_in_tile * 3);
                     g.pixel = (uint32_t)(t_j * P.width + t_x0 + p_in_tile);
                     g.sample = (uint32_t)smp;
-                    gen_camera_ray(P, g, key, t_x0 + p_in_tile, t_j, o, d);
+                    gen_camera_ray(P, F, g, key, t_x0 + p_in_tile, t_j, o, d);
                     thr = mk(1, 1, 1);
                     depth = P.max_depth;
                     has_path = true;
@@ -1029,7 +1076,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                         if (atomicSub(&bank_remaining[bank], 1) == 1) {
                             const int n_values = bank_values[bank];
                             const int out0 = bank_out[bank];
-                            for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * kBankValues + i]);
+                            for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * bank_vals + i]);
                         }
                     }
                 }
@@ -1042,18 +1089,18 @@ void mlrt_render_kernel(const KParams<real> P) {
                     wr.o = o; wr.d = d;
                     c.sr = slab_ray(wr);
                     phase = PH_TRAV;
-                    if (FEAT == 0 && P.primary_lists && depth == P.max_depth) {  // a fresh sample: its primary ray
-                        const int bank = pix / kBankValues;
-                        const int count = cand_count[bank];
+                    if (lists && depth == P.max_depth) {  // a fresh sample: its primary ray
+                        const int bank = pix >> kPixBankShift;
+                        const int count = cand[bank * kCandRecord];
                         if (count != kCandInvalid) {
-                            if (count > 0) { c.node = cand[bank * kCand]; depth |= kPrimaryFlag; phase = PH_SPECIAL; }
+                            if (count > 0) { c.node = cand[bank * kCandRecord + 1]; depth |= kPrimaryFlag; phase = PH_SPECIAL; }
                             else { c.node = n_nodes; phase = PH_SHADE; }  // nothing inside the tile's frustum: background
                         }
                     }
-                } else if (!has_path) {
-                    // no sample to be had right now: the stream is finished, or the ring is full (woken when a bank drains)
+                } else if (want) {
+                    // no sample to be had right now: the stream is finished, or every bank is taken (woken when one drains)
                     phase = (queue_done && t_next >= t_total) ? PH_IDLE : PH_WAIT;
-                }
+                }  // else (max_depth == 0): the lane's sample is already finished; it stays in PH_SHADE and asks again
             }
             n = fetch_entry(S, c.node, n_nodes);
         }
@@ -1114,6 +1161,11 @@ int occupancy_variant(size_t dyn_lds) {
 extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream) {
     const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
     int rc;
+    if (P.primary_lists) {
+        hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel, dim3((unsigned)((P.n_groups + 255) / 256)), dim3(256), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
+        rc = (int)hipGetLastError();
+        if (rc != 0) return rc;
+    }
     if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
                                      : MLRT_NS::launch_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream);
     else rc = lds_scene ? MLRT_NS::launch_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream)
@@ -1136,6 +1188,7 @@ extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
 extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
 extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }
 extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(void) { return MLRT_NS::kAccBytesPerWave; }
+extern "C" int MLRT_CAT(mlrt_lds_frame_bytes_, MLRT_SUFFIX)(void) { return MLRT_NS::kFrameParamBytes; }
 extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene, size_t dyn_lds) {
     if (variant == 1) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds);
     return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds);
