@@ -522,15 +522,19 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     }
     K.lens_radius = cam->lens_radius;
     K.has_lens = cam->lens_radius != 0.0 ? 1 : 0;
+    K.inv_wm1 = 1.0 / ((double)p->image_width - 1.0); K.inv_hm1 = 1.0 / ((double)p->image_height - 1.0);
     K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
     // Tile geometry (see KParams).  Big chunks of ~MLRT_TILE_SAMPLES samples (default 512): enough to keep 64 lanes busy
-    // through a tile's ramp-up, with per-tile work (queue atomics, the primary candidate list) small against it.  The last
-    // samples of every pixel go out in the tapering passes of MLRT_TILE_TAIL (sizes from the END of the sample range,
-    // default "64,64,128"): the integer accumulation makes the split invisible in the image.  Low spp: several pixels per
-    // tile and a single pass.
+    // through a tile's ramp-up, with per-tile work (queue atomics, the candidate record) small against it.  The last
+    // samples of every pixel go out in tapering passes (sizes from the END of the sample range; MLRT_TILE_TAIL overrides):
+    // the integer accumulation makes the split invisible in the image.  How deep the taper goes follows the number of
+    // big tiles per wave - the fewer, the larger the share of the frame time one late heavy tile is (measured, kernel ms
+    // for 1/1, 1/2, 1/4, 1/8 of C2's rows: no taper 47.6 25.0 14.1 8.6; "128" 48.4 24.7 13.1 7.8; "64,128" 49.5 25.2 13.1
+    // 7.5; "64,64,128" 50.6 25.7 13.4 7.1) - and a small tile costs the FULL variant's expensive samples relatively less.
+    // Low spp: several pixels per tile and a single pass.
     int target = 512;
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
     const int spp = p->samples_per_pixel;
@@ -540,7 +544,12 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     if (spp >= 128) {
         std::vector<int> tail;  // from the end
         const char* spec = std::getenv("MLRT_TILE_TAIL");
-        for (const char* q = spec ? spec : "64,64,128"; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
+        if (!spec) {
+            const double waves = (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64);
+            const double big_tiles_per_wave = (double)p->image_width * n_rows * ((spp + target - 1) / target) / waves / (c->variant == 1 ? 1.0 : 2.0);
+            spec = big_tiles_per_wave >= 128 ? "" : big_tiles_per_wave >= 64 ? "128" : big_tiles_per_wave >= 32 ? "64,128" : big_tiles_per_wave >= 16 ? "64,64,128" : "64,64,64,64,128";
+        }
+        for (const char* q = spec; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
             const int v = std::atoi(q);
             if (v > 0) tail.push_back(v);
             while (*q && *q != ',') q++;
@@ -566,6 +575,15 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.pix_per_tile = pix;
     K.tiles_per_row = (p->image_width + pix - 1) / pix;
     K.n_groups = K.tiles_per_row * n_rows;
+    auto magic = [](int32_t d, uint32_t& m, int32_t& shift) {  // floor(n / d) = mulhi(n, m) >> shift for 0 <= n < 2^31 (tests/test_abi.py checks the rule)
+        if (d <= 1) { m = 0u; shift = -1; return; }
+        int L = 0;
+        while (((int64_t)1 << L) < d) L++;
+        m = (uint32_t)((((uint64_t)1 << (31 + L)) / (uint64_t)d) + 1u);
+        shift = L - 1;
+    };
+    magic(K.n_groups, K.n_groups_magic, K.n_groups_shift);
+    magic(K.tiles_per_row, K.tiles_per_row_magic, K.tiles_per_row_shift);
     const int64_t n_tiles64 = (int64_t)K.n_groups * (K.n_big + K.n_tail);
     MLRT_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
     K.n_tiles = (int32_t)n_tiles64;

@@ -86,7 +86,8 @@ struct KParams {
     const DImage* images;
     // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
-    double lens_radius;  // (cam_origin ... lens_radius stay contiguous: the kernel copies them as 19 doubles)
+    double lens_radius;
+    double inv_wm1, inv_hm1;  // 1 / (width - 1), 1 / (height - 1)  (cam_origin ... inv_hm1 stay contiguous: the kernel copies them as 21 doubles)
     int32_t has_lens;    // lens_radius != 0
     int32_t width, height, spp, max_depth;
     uint32_t seed_lo, seed_hi;
@@ -100,6 +101,10 @@ struct KParams {
     const int32_t* rows;  // device array of row indices or nullptr (= identity)
     int32_t n_rows, pix_per_tile, tiles_per_row, n_groups, n_big, big, n_tail, n_tiles;
     int32_t tail_s0[kMaxTailPasses + 1];
+    // n / n_groups and n / tiles_per_row for n < 2^31 as mulhi(n, magic) >> shift (shift < 0: divisor 1): a scalar integer
+    // division is ~35 instructions, and a wave opening a tile executes them with all 64 lanes waiting
+    uint32_t n_groups_magic, tiles_per_row_magic;
+    int32_t n_groups_shift, tiles_per_row_shift;
     int32_t n_banks, bank_values;  // the wave's LDS accumulator area: n_banks banks of bank_values (= 3 * pix_per_tile) sums
     unsigned long long* acc_global;  // [n_rows][W][3] 2^-32 fixed-point colour sums (integer adds: order independent)
     int32_t* rgb_out;     // [n_rows][W][3], written by the resolve kernel

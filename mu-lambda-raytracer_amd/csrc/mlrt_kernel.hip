@@ -86,13 +86,14 @@ constexpr int kPixBankShift = 10;      // `pix` = bank << 10 | index of the pixe
 // registers for the whole kernel (the compiler hoists the loads), which spilled scalar registers into vector lanes.
 struct FrameParams {
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
-    double lens_radius;
+    double lens_radius, inv_wm1, inv_hm1;
     MLRT_REAL bg_top[3], bg_bottom[3];
 };
-constexpr int kFrameParamBytes = 208;
+constexpr int kFrameParamBytes = 224;
 static_assert(sizeof(FrameParams) <= kFrameParamBytes, "FrameParams must fit its LDS slot");
 
 // ---------------------------------------------------------------------------------------------- math helpers
+DEV int magic_div(int n, uint32_t magic, int shift) { return shift < 0 ? n : (int)(__umulhi((uint32_t)n, magic) >> shift); }  // KParams: n / divisor
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV double fast_rcp(double x) { return 1.0 / x; }
 DEV float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -705,8 +706,9 @@ DEV V3 background_color(const KParams<real>& P, const FrameParams& F, P3 d) {  /
 DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
     rng_fill(g, key, 0u);
     g.draw = 4u;
-    const double s = ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
-    const double t = ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
+    // (fast build: times the reciprocal - an f64 division is ~25 instructions, twice per sample)
+    const double s = kFast ? ((double)i + u01d(g.b0)) * F.inv_wm1 : ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
+    const double t = kFast ? ((double)j + u01d(g.b1)) * F.inv_hm1 : ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
     double rdx = 0.0, rdy = 0.0;
     if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
         const double u1 = ((double)(g.b2 >> 8) + 1.0) * (1.0 / 16777216.0);
@@ -726,11 +728,20 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
 
 // 2^-32 fixed point; integer accumulation is order independent (within a tile in LDS, across tiles in HBM).  NaN/negative radiance cannot occur on this
 // path (near_zero guard, abs() under the refraction root); they are clamped to 0 rather than poisoning the sum.
-DEV unsigned long long to_fixed(real c) {
-    double x = (double)c;
+DEV unsigned long long to_fixed(double c) {
+    double x = c;
     if (!(x > 0.0)) x = 0.0;
     if (x > 1048576.0) x = 1048576.0;
     return (unsigned long long)(x * 4294967296.0 + 0.5);
+}
+// Fast build: the same fixed point from f32 with five 32-bit instructions per channel instead of the f64 -> u64 sequence
+// (three conversions per finished sample): whole part and fraction converted separately, both exact (c - trunc(c) and the
+// scaling by 2^32 are exact in f32), truncating the bits below 2^-32.  v_cvt_u32_f32 maps NaN and negatives to 0 and
+// saturates, which is the clamp.
+DEV unsigned long long to_fixed(float c) {
+    const uint32_t whole = (uint32_t)c;
+    const uint32_t frac = (uint32_t)((c - (float)whole) * 4294967296.0f);
+    return ((unsigned long long)whole << 32) | (unsigned long long)frac;
 }
 
 #ifndef MLRT_BOX_SPECIAL
@@ -849,7 +860,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         acc_base = smem;
     }
     FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytesPerWave);
-    if (threadIdx.x < 19) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... lens_radius are contiguous in both structs
+    if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... inv_hm1 are contiguous in both structs
     if (threadIdx.x < 3) { F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x]; }
     __syncthreads();
     Scene S;
@@ -1025,9 +1036,9 @@ void mlrt_render_kernel(const KParams<real> P) {
                     const int tile = queue_pop();
                     if (tile >= P.n_tiles) { queue_done = true; break; }
                     // tile -> (pass, pixel group): chunk-major queue, see KParams
-                    const int pass = tile / P.n_groups;
+                    const int pass = magic_div(tile, P.n_groups_magic, P.n_groups_shift);
                     const int group = tile - pass * P.n_groups;
-                    const int row_k = group / P.tiles_per_row;
+                    const int row_k = magic_div(group, P.tiles_per_row_magic, P.tiles_per_row_shift);
                     t_x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
                     const int npix = min(P.pix_per_tile, P.width - t_x0);
                     if (pass < P.n_big) {
@@ -1059,7 +1070,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                 const int avail = t_total - t_next;
                 if (want && rank < avail) {
                     const int q = t_next + rank;
-                    const int p_in_tile = q / t_ns;
+                    const int p_in_tile = P.pix_per_tile == 1 ? 0 : q / t_ns;  // (uniform branch: no per-lane integer division at high spp)
                     const int smp = t_s0 + (q - p_in_tile * t_ns);
                     pix = (t_bank << kPixBankShift) | (t_bank * bank_vals + p_in_tile * 3);
                     g.pixel = (uint32_t)(t_j * P.width + t_x0 + p_in_tile);
