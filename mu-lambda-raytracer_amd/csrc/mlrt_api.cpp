@@ -502,6 +502,75 @@ void destroy(mlrt_context* c) {
     delete c;
 }
 
+// The frame's tile queue (KParams), planned from the frame size and the number of resident waves alone: a plain function so
+// that the CPU tests can check it (mlrt_debug_tile_plan): every sample of every pixel group in exactly one tile.
+struct TilePlan {
+    int32_t pix_per_tile, tiles_per_row, n_groups, n_big, big, n_tail;
+    int32_t tail_s0[mlrt::kMaxTailPasses + 1];
+    int64_t n_tiles;
+    uint32_t n_groups_magic, tiles_per_row_magic;
+    int32_t n_groups_shift, tiles_per_row_shift;
+};
+void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, TilePlan& T) {
+    // Tile geometry (see KParams).  Big chunks of ~MLRT_TILE_SAMPLES samples (default 512): enough to keep 64 lanes busy
+    // through a tile's ramp-up, with per-tile work (queue atomics, the candidate record) small against it.  The last
+    // samples of every pixel go out in tapering passes (sizes from the END of the sample range; MLRT_TILE_TAIL overrides):
+    // the integer accumulation makes the split invisible in the image.  How deep the taper goes follows the number of
+    // big tiles per wave - the fewer, the larger the share of the frame time one late heavy tile is (measured, kernel ms
+    // for 1/1, 1/2, 1/4, 1/8 of C2's rows: no taper 47.6 25.0 14.1 8.6; "128" 48.4 24.7 13.1 7.8; "64,128" 49.5 25.2 13.1
+    // 7.5; "64,64,128" 50.6 25.7 13.4 7.1) - and a small tile costs the FULL variant's expensive samples relatively less.
+    // Low spp: several pixels per tile and a single pass.
+    int target = 512;
+    if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
+    int pix = 1;
+    T.n_big = 1; T.big = spp; T.n_tail = 0;
+    for (int k = 0; k <= mlrt::kMaxTailPasses; k++) T.tail_s0[k] = spp;
+    if (spp >= 128) {
+        std::vector<int> tail;  // from the end
+        const char* spec = std::getenv("MLRT_TILE_TAIL");
+        if (!spec) {
+            const double big_tiles_per_wave = (double)width * n_rows * ((spp + target - 1) / target) / waves / (lean ? 1.0 : 2.0);
+            spec = big_tiles_per_wave >= 128 ? "" : big_tiles_per_wave >= 64 ? "128" : big_tiles_per_wave >= 32 ? "64,128" : big_tiles_per_wave >= 16 ? "64,64,128" : "64,64,64,64,128";
+        }
+        for (const char* q = spec; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
+            const int v = std::atoi(q);
+            if (v > 0) tail.push_back(v);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        int tail_total = 0, n_tail = 0;
+        while (n_tail < (int)tail.size() && tail_total + tail[n_tail] <= spp - 64) tail_total += tail[n_tail++];  // the big passes keep >= 64 samples
+        const int rest = spp - tail_total;
+        T.n_big = (rest + target - 1) / target;
+        T.big = rest / T.n_big;  // the remainder (< n_big samples) joins the first tail pass, or is one more small pass
+        // queue order: the big passes, then tail[n_tail-1] ... tail[0]; the first pass after the big ones starts where they end
+        T.n_tail = n_tail;
+        if (n_tail == 0 && T.n_big * T.big < spp) T.n_tail = 1;
+        T.tail_s0[0] = T.n_big * T.big;
+        for (int k = 1, end = tail_total; k <= n_tail; k++) {
+            end -= tail[n_tail - k];
+            T.tail_s0[k] = spp - end;
+        }
+    } else {
+        pix = std::min(4, std::max(1, (target + spp / 2) / spp));  // nearest whole number of pixels (kMaxPixPerTile)
+        pix = std::min(pix, width);
+    }
+    T.pix_per_tile = pix;
+    T.tiles_per_row = (width + pix - 1) / pix;
+    T.n_groups = T.tiles_per_row * n_rows;
+    auto magic = [](int32_t d, uint32_t& m, int32_t& shift) {  // floor(n / d) = mulhi(n, m) >> shift for 0 <= n < 2^31 (tests/test_host_scene.py checks the rule)
+        if (d <= 1) { m = 0u; shift = -1; return; }
+        int L = 0;
+        while (((int64_t)1 << L) < d) L++;
+        m = (uint32_t)((((uint64_t)1 << (31 + L)) / (uint64_t)d) + 1u);
+        shift = L - 1;
+    };
+    magic(T.n_groups, T.n_groups_magic, T.n_groups_shift);
+    magic(T.tiles_per_row, T.tiles_per_row_magic, T.tiles_per_row_shift);
+    const int64_t n_tiles64 = (int64_t)T.n_groups * (T.n_big + T.n_tail);
+    T.n_tiles = n_tiles64;
+}
+
 bool primary_lists_wanted(const mlrt_context* c, const mlrt_camera* cam, int image_height) {
     return c->variant == 1 && cam->lens_radius == 0.0 && c->n_nodes <= 4096 && image_height < 65536 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr;
 }
@@ -527,66 +596,15 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
-    // Tile geometry (see KParams).  Big chunks of ~MLRT_TILE_SAMPLES samples (default 512): enough to keep 64 lanes busy
-    // through a tile's ramp-up, with per-tile work (queue atomics, the candidate record) small against it.  The last
-    // samples of every pixel go out in tapering passes (sizes from the END of the sample range; MLRT_TILE_TAIL overrides):
-    // the integer accumulation makes the split invisible in the image.  How deep the taper goes follows the number of
-    // big tiles per wave - the fewer, the larger the share of the frame time one late heavy tile is (measured, kernel ms
-    // for 1/1, 1/2, 1/4, 1/8 of C2's rows: no taper 47.6 25.0 14.1 8.6; "128" 48.4 24.7 13.1 7.8; "64,128" 49.5 25.2 13.1
-    // 7.5; "64,64,128" 50.6 25.7 13.4 7.1) - and a small tile costs the FULL variant's expensive samples relatively less.
-    // Low spp: several pixels per tile and a single pass.
-    int target = 512;
-    if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
-    const int spp = p->samples_per_pixel;
-    int pix = 1;
-    K.n_big = 1; K.big = spp; K.n_tail = 0;
-    for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = spp;
-    if (spp >= 128) {
-        std::vector<int> tail;  // from the end
-        const char* spec = std::getenv("MLRT_TILE_TAIL");
-        if (!spec) {
-            const double waves = (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64);
-            const double big_tiles_per_wave = (double)p->image_width * n_rows * ((spp + target - 1) / target) / waves / (c->variant == 1 ? 1.0 : 2.0);
-            spec = big_tiles_per_wave >= 128 ? "" : big_tiles_per_wave >= 64 ? "128" : big_tiles_per_wave >= 32 ? "64,128" : big_tiles_per_wave >= 16 ? "64,64,128" : "64,64,64,64,128";
-        }
-        for (const char* q = spec; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
-            const int v = std::atoi(q);
-            if (v > 0) tail.push_back(v);
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
-        }
-        int tail_total = 0, n_tail = 0;
-        while (n_tail < (int)tail.size() && tail_total + tail[n_tail] <= spp - 64) tail_total += tail[n_tail++];  // the big passes keep >= 64 samples
-        const int rest = spp - tail_total;
-        K.n_big = (rest + target - 1) / target;
-        K.big = rest / K.n_big;  // the remainder (< n_big samples) joins the first tail pass, or is one more small pass
-        // queue order: the big passes, then tail[n_tail-1] ... tail[0]; the first pass after the big ones starts where they end
-        K.n_tail = n_tail;
-        if (n_tail == 0 && K.n_big * K.big < spp) K.n_tail = 1;
-        K.tail_s0[0] = K.n_big * K.big;
-        for (int k = 1, end = tail_total; k <= n_tail; k++) {
-            end -= tail[n_tail - k];
-            K.tail_s0[k] = spp - end;
-        }
-    } else {
-        pix = std::min(4, std::max(1, (target + spp / 2) / spp));  // nearest whole number of pixels (kMaxPixPerTile)
-        pix = std::min(pix, (int)p->image_width);
-    }
-    K.pix_per_tile = pix;
-    K.tiles_per_row = (p->image_width + pix - 1) / pix;
-    K.n_groups = K.tiles_per_row * n_rows;
-    auto magic = [](int32_t d, uint32_t& m, int32_t& shift) {  // floor(n / d) = mulhi(n, m) >> shift for 0 <= n < 2^31 (tests/test_abi.py checks the rule)
-        if (d <= 1) { m = 0u; shift = -1; return; }
-        int L = 0;
-        while (((int64_t)1 << L) < d) L++;
-        m = (uint32_t)((((uint64_t)1 << (31 + L)) / (uint64_t)d) + 1u);
-        shift = L - 1;
-    };
-    magic(K.n_groups, K.n_groups_magic, K.n_groups_shift);
-    magic(K.tiles_per_row, K.tiles_per_row_magic, K.tiles_per_row_shift);
-    const int64_t n_tiles64 = (int64_t)K.n_groups * (K.n_big + K.n_tail);
-    MLRT_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
-    K.n_tiles = (int32_t)n_tiles64;
+    TilePlan T;
+    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant == 1, T);
+    MLRT_REQUIRE(T.n_tiles < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
+    K.pix_per_tile = T.pix_per_tile; K.tiles_per_row = T.tiles_per_row; K.n_groups = T.n_groups; K.n_big = T.n_big; K.big = T.big; K.n_tail = T.n_tail;
+    for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = T.tail_s0[k];
+    K.n_tiles = (int32_t)T.n_tiles;
+    K.n_groups_magic = T.n_groups_magic; K.n_groups_shift = T.n_groups_shift;
+    K.tiles_per_row_magic = T.tiles_per_row_magic; K.tiles_per_row_shift = T.tiles_per_row_shift;
+    const int pix = T.pix_per_tile;
     {   // cut the wave's accumulator area (mlrt_kernel.hip kAccBytesPerWave) into banks: sums + remaining/out/values + candidate list
         const int area = c->precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64();
         K.bank_values = 3 * pix;
@@ -679,6 +697,16 @@ int32_t guarded(F&& f) {
 
 extern "C" {
 
+// Test hook (not part of include/mlrt.h): the tile plan of a frame.  out = pix_per_tile, tiles_per_row, n_groups, n_big, big, n_tail,
+// tail_s0[0..8], n_tiles, n_groups_magic, n_groups_shift, tiles_per_row_magic, tiles_per_row_shift  (20 values)
+void mlrt_debug_tile_plan(int32_t width, int32_t n_rows, int32_t spp, int32_t waves, int32_t lean, int64_t* out) {
+    TilePlan T;
+    plan_tiles(width, n_rows, spp, (double)waves, lean != 0, T);
+    int k = 0;
+    out[k++] = T.pix_per_tile; out[k++] = T.tiles_per_row; out[k++] = T.n_groups; out[k++] = T.n_big; out[k++] = T.big; out[k++] = T.n_tail;
+    for (int i = 0; i <= mlrt::kMaxTailPasses; i++) out[k++] = T.tail_s0[i];
+    out[k++] = T.n_tiles; out[k++] = T.n_groups_magic; out[k++] = T.n_groups_shift; out[k++] = T.tiles_per_row_magic; out[k++] = T.tiles_per_row_shift;
+}
 void mlrt_version(int32_t* major, int32_t* minor) {
     if (major) *major = MLRT_VERSION_MAJOR;
     if (minor) *minor = MLRT_VERSION_MINOR;

@@ -172,3 +172,50 @@ def test_p3_writer_matches_reference_format(mlrt, tmp_path):
     assert text[:3] == ["P3", "3 2", "255"]
     assert text[3:9] == ["9 10 11", "12 13 14", "15 16 17", "0 1 2", "3 4 5", "6 7 8"]
     assert text[9] == ""
+
+
+def _tile_plan(mlrt, width, n_rows, spp, waves, lean):
+    import ctypes as C
+    out = (C.c_int64 * 20)()
+    f = mlrt.lib().mlrt_debug_tile_plan
+    f.restype = None
+    f(C.c_int32(width), C.c_int32(n_rows), C.c_int32(spp), C.c_int32(waves), C.c_int32(1 if lean else 0), out)
+    v = [int(x) for x in out]
+    return dict(pix=v[0], tiles_per_row=v[1], n_groups=v[2], n_big=v[3], big=v[4], n_tail=v[5], tail_s0=v[6:15], n_tiles=v[15],
+                g_magic=v[16], g_shift=v[17], r_magic=v[18], r_shift=v[19])
+
+
+@pytest.mark.parametrize("width,n_rows,spp,waves,lean", [
+    (1200, 800, 500, 6144, True), (1200, 100, 500, 6144, True), (1200, 1, 500, 6144, True), (800, 800, 1000, 4096, False),
+    (800, 100, 10000, 4096, False), (400, 266, 8, 6144, True), (131, 87, 3, 1024, True), (64, 1, 5000, 1024, True),
+    (150, 100, 300, 6144, True), (2, 2, 1, 4096, False), (7, 5, 127, 64, True), (7, 5, 128, 64, True), (7, 5, 129, 64, False),
+    (1200, 800, 191, 6144, True), (1200, 800, 192, 6144, True), (33, 9, 16777216, 4096, True)])
+def test_tile_plan_hands_out_every_sample_once(mlrt, width, n_rows, spp, waves, lean):
+    """The frame's tile queue (chunk-major passes, tapering at the end): the passes partition [0, spp) of every pixel group, the
+    pixel groups partition every row, and the multiply-shift the kernel divides tile numbers with is exact."""
+    t = _tile_plan(mlrt, width, n_rows, spp, waves, lean)
+    assert 1 <= t["pix"] <= 4 and t["tiles_per_row"] == -(-width // t["pix"]) and t["n_groups"] == t["tiles_per_row"] * n_rows
+    if spp >= 128:
+        assert t["pix"] == 1
+    passes = [(k * t["big"], t["big"]) for k in range(t["n_big"])] + [(t["tail_s0"][k], t["tail_s0"][k + 1] - t["tail_s0"][k]) for k in range(t["n_tail"])]
+    pos = 0
+    for s0, ns in passes:
+        assert s0 == pos and ns > 0
+        pos += ns
+    assert pos == spp
+    assert t["n_tiles"] == t["n_groups"] * len(passes)
+    if t["n_tail"]:
+        sizes = [ns for _, ns in passes[t["n_big"]:]]
+        assert sizes[-1] <= 128 and all(a >= b for a, b in zip(sizes[:-1], sizes[1:])) or t["n_tail"] == 1  # the queue ends on its smallest tiles
+    rng = np.random.default_rng(width * 7919 + spp)
+    for d, magic, shift in ((t["n_groups"], t["g_magic"], t["g_shift"]), (t["tiles_per_row"], t["r_magic"], t["r_shift"])):
+        ns = np.concatenate([np.array([0, 1, d - 1, d, d + 1, 2**31 - 1], dtype=np.int64), rng.integers(0, 2**31, 2000), np.arange(0, 40) * d, np.arange(1, 40) * d - 1])
+        ns = ns[(ns >= 0) & (ns < 2**31)]
+        got = ns if shift < 0 else ((ns * magic) >> 32) >> shift
+        assert np.array_equal(got, ns // d), d
+
+
+def test_tile_plan_tapers_more_when_the_frame_is_small_against_the_gpu(mlrt):
+    """Few big tiles per wave -> more of the pixel's last samples go out in small tiles (strong scaling: 1/8 of the rows per GPU)."""
+    depth = [_tile_plan(mlrt, 1200, rows, 500, 6144, True)["n_tail"] for rows in (800, 400, 200, 100, 25)]
+    assert depth == sorted(depth) and depth[0] == 0 and depth[-1] >= 3
