@@ -572,7 +572,7 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, TilePla
 }
 
 bool primary_lists_wanted(const mlrt_context* c, const mlrt_camera* cam, int image_height) {
-    return c->variant == 1 && cam->lens_radius == 0.0 && c->n_nodes <= 4096 && image_height < 65536 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr;
+    return c->variant == 1 && c->n_nodes <= 4096 && image_height < 65536 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr;
 }
 
 template <typename R>
@@ -616,8 +616,8 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.n_queues = 8;
     if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) { const int v = std::atoi(nq); if (v >= 1 && v <= mlrt::kMaxQueues && (v & (v - 1)) == 0) K.n_queues = v; }
     K.stats = c->d_stats;
-    // per-pixel-group primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, a pinhole camera, and few
-    // enough entries that the pre-pass's flat scan stays small against the frame
+    // per-pixel-group primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, and few enough entries that
+    // the pre-pass's flat scan stays small against the frame
     K.primary_lists = primary_lists_wanted(c, cam, p->image_height) ? c->d_cand : nullptr;
     K.debug_pixel = -1; K.debug_sample = -1;
     if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }

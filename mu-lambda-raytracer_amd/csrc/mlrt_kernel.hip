@@ -351,7 +351,9 @@ DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) 
 // Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in BOTH builds: with the radius-1000 ground
 // sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
 // the f32 rate, so this is affordable; the fast build avoids the f64 divide and square-root sequences.
-DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+// The quadratic of Sphere::hit: discriminant >= 0, and its two roots evaluated exactly as sphere_hit's callers always did
+// (near root first; the far root by the same expression with the sign of the square root flipped).
+DEV bool sphere_roots(const DNode<real>& n, const Ray& r, double& near_root, double& far_root) {
 #pragma clang fp contract(off)
     const double ocx = r.o.x - (double)n.v[0], ocy = r.o.y - (double)n.v[1], ocz = r.o.z - (double)n.v[2];
     const double radius = (double)n.v[3];
@@ -359,7 +361,7 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
     const double c = dfma(ocz, ocz, dfma(ocy, ocy, ocx * ocx)) - radius * radius;   // oc.length_squared() - r*r
     const double discriminant = dfma(half_b, half_b, -(r.a * c));                   // half_b*half_b - a*c
     if (discriminant < 0.0) return false;
-    double sqrtd, root;
+    double sqrtd;
     if (kFast) {
         // sqrt to ~f64 accuracy: f32 rsqrt seed, one Newton step on y = 1/sqrt(x), then s = x*y corrected once
         if (discriminant == 0.0) {
@@ -371,18 +373,21 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
             s = dfma(0.5 * y, dfma(-s, s, discriminant), s);
             sqrtd = s;
         }
-        root = (-half_b - sqrtd) * r.inv_a;
-        if (root < tmin || tmax < root) {
-            root = (-half_b + sqrtd) * r.inv_a;
-            if (root < tmin || tmax < root) return false;
-        }
+        near_root = (-half_b - sqrtd) * r.inv_a;
+        far_root = (-half_b + sqrtd) * r.inv_a;
     } else {
         sqrtd = sqrt(discriminant);
-        root = (-half_b - sqrtd) / r.a;
-        if (root < tmin || tmax < root) {
-            root = (-half_b + sqrtd) / r.a;
-            if (root < tmin || tmax < root) return false;
-        }
+        near_root = (-half_b - sqrtd) / r.a;
+        far_root = (-half_b + sqrtd) / r.a;
+    }
+    return true;
+}
+DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+    double root, far_root;
+    if (!sphere_roots(n, r, root, far_root)) return false;
+    if (root < tmin || tmax < root) {
+        root = far_root;
+        if (root < tmin || tmax < root) return false;
     }
     t_out = root;
     return true;
@@ -469,7 +474,15 @@ DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3
         // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
         const DNode<real> boundary = S.nodes[c.node + 1];
         double t1, t2; int aux = 0;
-        if (prim_hit<FEAT>(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit<FEAT>(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux)) {
+        bool through;
+        if ((boundary.tag & TAG_KIND_MASK) == TAG_SPHERE) {
+            // boundary.hit(-inf, inf) is the near root and boundary.hit(t1 + 0.001, inf) the far one when it is not below
+            // t1 + 0.001 (shapes.rs:66-73): ONE evaluation of the quadratic instead of two identical ones
+            through = sphere_roots(boundary, r, t1, t2) && !(t2 < t1 + 0.001);
+        } else {
+            through = prim_hit<FEAT>(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit<FEAT>(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux);
+        }
+        if (through) {
             t1 = fmax(t1, t_min);
             t2 = fmin(t2, c.closest);
             if (t1 < t2) {
@@ -764,7 +777,7 @@ DEV void pin_entry(const DNode<real>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
-// Primary rays of a pixel group (1-4 neighbouring pixels, pinhole camera) all lie inside the pyramid from the camera
+// Primary rays of a pixel group (1-4 neighbouring pixels; pinhole camera, for a thin lens see below) all lie inside the pyramid from the camera
 // origin through the group's footprint on the image plane, so they can only hit the spheres that touch that pyramid:
 // typically the ground and one or two others.  A pre-pass (one thread per pixel group, once per frame) scans the entry
 // array (sphere against the four side planes, outward margins) and leaves the touching sphere entries, in entry order,
@@ -803,6 +816,12 @@ __global__ void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* recor
     };
     const V3 n_left = plane(d00, d01), n_right = plane(d10, d11), n_bottom = plane(d00, d10), n_top = plane(d01, d11);
     const V3 of = mk((real)org.x, (real)org.y, (real)org.z);
+    // Thin lens (camera.rs:41-47): a ray leaves origin + delta, |delta| <= lens_radius, towards the point its pinhole twin hits
+    // on the focus plane, so at distance t it is |delta| * |1 - t / f| away from that twin, f >= focus_dist the twin's distance
+    // to the focus plane: the spheres it can hit are within lens_radius * max(1, t / focus_dist) of the pinhole pyramid.
+    const P3 fw = mkp(-base.x - 0.5 * hor.x - 0.5 * ver.x, -base.y - 0.5 * hor.y - 0.5 * ver.y, -base.z - 0.5 * hor.z - 0.5 * ver.z);  // focus_dist * w
+    const real lens = (real)(P.lens_radius * 1.001);
+    const real inv_focus = P.has_lens ? (real)(1.0 / sqrt(fw.x * fw.x + fw.y * fw.y + fw.z * fw.z)) : (real)0;
     uint16_t list[kCandRecord];
 #pragma unroll
     for (int k = 0; k < kCandRecord; k++) list[k] = 0;
@@ -811,7 +830,8 @@ __global__ void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* recor
         const DNode<real> q = nodes[e];
         if ((q.tag & TAG_KIND_MASK) != TAG_SPHERE) continue;
         const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
-        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * (abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z));
+        const real far = abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z);  // >= |cc|
+        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * far + lens * max_r((real)1, (far + abs_r(q.v[3])) * inv_focus);
         if (dot(n_left, cc) >= -reach && dot(n_right, cc) >= -reach && dot(n_bottom, cc) >= -reach && dot(n_top, cc) >= -reach) {
 #pragma unroll
             for (int k = 0; k < kCand; k++) if (k == count) list[1 + k] = (uint16_t)e;
