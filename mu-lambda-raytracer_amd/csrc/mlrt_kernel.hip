@@ -202,8 +202,9 @@ DEV uint32_t rng_next(Rng& g, RngKey key) {
     return i == 0 ? g.b0 : (i == 1 ? g.b1 : (i == 2 ? g.b2 : g.b3));
 }
 // The words of one Material::scatter.  Contract (mirrored by the oracle's PhiloxStream::begin_scatter/end_scatter): a
-// scatter starts on a block boundary and consumes its whole block, whatever the material draws from it (Lambertian /
-// Metal / Isotropic: words 0-2, the unit-ball sample; Dielectric: word 0 when it can refract, materials.rs:98).  So a
+// scatter starts on a block boundary and owns words 0-2 of its block, whatever the material draws from them (Lambertian /
+// Metal / Isotropic: the unit-ball sample; Dielectric: word 0 when it can refract, materials.rs:98); word 3 is the next
+// draw of the stream (the first ConstantMedium draw of the scattered ray, which so needs no Philox of its own).  So a
 // shading batch runs Philox exactly once, with no refill branch and no word selection; and in a scene without media
 // (whose draws happen during traversal, volumes.rs:47) the block number is just 1 + the bounce number: the stream
 // position is not per-lane state at all.
@@ -212,7 +213,7 @@ DEV void rng_scatter_words(Rng& g, RngKey key, int bounce, uint32_t& w0, uint32_
     const uint32_t block = (FEAT & FEAT_MEDIUM) ? (g.draw + 3u) >> 2 : 1u + (uint32_t)bounce;
     uint32_t w3;
     philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, w0, w1, w2, w3);
-    if (FEAT & FEAT_MEDIUM) g.draw = (block + 1u) << 2;
+    if (FEAT & FEAT_MEDIUM) { g.draw = (block << 2) + 3u; g.b3 = w3; }
 }
 DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
 DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
@@ -487,12 +488,24 @@ DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3
             t2 = fmin(t2, c.closest);
             if (t1 < t2) {
                 t1 = fmax(t1, 0.0);
-                const double ray_scale = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);  // r.dir.length() of the WORLD ray
+                // r.dir.length() of the WORLD ray and its reciprocal; fast build: f32 rsqrt seed + Newton instead of the f64
+                // square root and division sequences
+                const double dd = d.x * d.x + d.y * d.y + d.z * d.z;
+                double ray_scale, inv_ray_scale = 0.0;
+                if (kFast) {
+                    double y = (double)__builtin_amdgcn_rsqf((float)dd);
+                    y = y * dfma(-0.5 * dd, y * y, 1.5);
+                    y = y * dfma(-0.5 * dd, y * y, 1.5);
+                    inv_ray_scale = y;
+                    ray_scale = dd * y;
+                } else {
+                    ray_scale = sqrt(dd);
+                }
                 const double distance_inside = (t2 - t1) * ray_scale;
                 const double xi = u01d(rng_next(g, key));
                 const double hit_distance = (double)n.v[0] * (kFast ? (double)logf((float)xi) : log(xi));
                 if (!(hit_distance > distance_inside)) {
-                    c.closest = t1 + hit_distance / ray_scale;
+                    c.closest = kFast ? dfma(hit_distance, inv_ray_scale, t1) : t1 + hit_distance / ray_scale;
                     c.hit_node = c.node; c.hit_aux = 0; c.hit_xf = c.xf;
                 }
             }

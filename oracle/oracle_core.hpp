@@ -98,8 +98,8 @@ struct Ray {  // vec.rs:215-228
 //    their published algorithms and pinned by the pcg64 demo vector + SURVEY.md section 8c known answers.
 //  * PhiloxStream: Philox4x32-10 (Salmon et al., SC'11), the DEVICE's generator: one stream per
 //    (pixel, sample); draw k is 32-bit word k%4 of block k/4; uniform = (word >> 8) * 2^-24.  A Material::scatter
-//    starts on a block boundary and consumes its whole block (begin_scatter/end_scatter), so the device evaluates
-//    Philox exactly once per scatter with no per-lane refill logic.
+//    starts on a block boundary and owns words 0-2 of its block, the draw after it is word 3 (begin_scatter /
+//    end_scatter), so the device evaluates Philox exactly once per scatter with no per-lane refill logic.
 //    The HIP kernel consumes the identical words in the identical order, which makes
 //    oracle[Philox] vs GPU[Philox] comparable sample for sample.
 // ------------------------------------------------------------------------------------------------
@@ -207,7 +207,14 @@ struct PhiloxStream : Rng {
         if ((draw & 3) != 0) draw = (draw + 3u) & ~3u;  // the next draw refills
         scatter_start = draw;
     }
-    void end_scatter() override { draw = scatter_start + 4u; }
+    // the scatter owns words 0-2 of its block; word 3 is the next draw of the stream (a medium draw of the scattered ray)
+    void end_scatter() override {
+        if (draw == scatter_start) {  // nothing drawn (Dielectric that cannot refract, a light): the block is still this scatter's
+            uint32_t ctr[4] = {scatter_start >> 2, sample, pixel, 0};
+            philox4x32_10(key, ctr, buf);
+        }
+        draw = scatter_start + 3u;
+    }
     PhiloxStream(uint64_t seed, uint32_t pixel_, uint32_t sample_) : pixel(pixel_), sample(sample_), draw(0) {
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
     }
