@@ -416,6 +416,7 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
         const mlrt_material& m = s.materials[i];
         DMaterial<R> d{};
         d.kind = m.kind | (texture_needs_uv(s, m.texture, 0) ? MATFLAG_NEEDS_UV : 0);
+        if (m.texture >= 0 && s.textures[m.texture].kind == MLRT_TEX_NOISE && (m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC)) d.kind |= MATFLAG_NOISE;
         d.tex = m.texture;
         for (int k = 0; k < 3; k++) d.albedo[k] = (R)m.albedo[k];
         // a scene whose textures are all SolidColor (the LEAN kernel variant) carries the colour in the material and no

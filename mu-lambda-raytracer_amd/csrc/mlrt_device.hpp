@@ -45,7 +45,7 @@ struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
 static_assert(sizeof(DNode<float>) == 32, "f32 entry must be 32 bytes (two ds_read_b128)");
 static_assert(sizeof(DNode<double>) == 64, "f64 entry is one 64-byte line");
 
-enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8 };
+enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8, MATFLAG_NOISE = 1 << 9 };  // NOISE: the material's own texture is a NoiseTexture
 
 // Scene features a kernel variant must support (the packer records which ones a scene uses; the launcher picks the
 // leanest compiled variant that covers them: fewer registers -> more waves per SIMD, less dead code in the hot loop).

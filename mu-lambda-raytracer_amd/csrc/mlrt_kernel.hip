@@ -552,17 +552,49 @@ DEV real perlin_turbulence(const Scene& S, int table, V3 p) {  // textures.rs:76
     return abs_r(accum);
 }
 // A scene of SolidColor textures only has the colour in the material (`solid`) and no texture table (mlrt_api.cpp pack).
+// The same turbulence for ONE point with the whole wave: its 7 octaves x 8 lattice corners are 56 independent terms, one
+// per lane, summed by a butterfly.  A marble hit is rare (0.07 per sample of final_scene) but half of the shading batches
+// have one, and the serial evaluation above is ~1000 instructions the other lanes of the batch wait through; this is ~80.
+// Call in wave-uniform control flow with a uniform point.  Fast build only: the order of the sum differs from
+// textures.rs:76-134 in the last bits (the parity build keeps the serial order).
+DEV float wave_turbulence(const Scene& S, int table, float px, float py, float pz, int lane) {
+    const int octave = lane >> 3;
+    const int di = (lane >> 2) & 1, dj = (lane >> 1) & 1, dk = lane & 1;
+    const float s = (float)(1 << (octave & 7));
+    const float qx = px * s, qy = py * s, qz = pz * s;  // textures.rs:84: p doubles per octave
+    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+    const float u = qx - fx, v = qy - fy, w = qz - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+    const real* vec = S.perlin_vec + (size_t)table * 3072;
+    const uint16_t* perm = S.perlin_perm + (size_t)table * 3072;
+    const int idx = perm[(i + di) & 1023] ^ perm[1024 + ((j + dj) & 1023)] ^ perm[2048 + ((k + dk) & 1023)];
+    const float cx = (float)vec[idx * 3], cy = (float)vec[idx * 3 + 1], cz = (float)vec[idx * 3 + 2];
+    const float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+    float term = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww) * (wx * cx + wy * cy + wz * cz);
+    term = octave < 7 ? term / s : 0.0f;  // textures.rs:83: the weight halves per octave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off);
+    return fabsf(term);
+}
 template <uint32_t FEAT>
-DEV V3 texture_value(const Scene& S, int tex, V3 solid, real u, real v, V3 p) {
+DEV V3 texture_value(const Scene& S, int tex, V3 solid, real u, real v, V3 p, bool have_turbulence = false, real turbulence = (real)0) {
     if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_NOISE | FEAT_TEX_CHECKER)) == 0) return solid;
     DTexture<real> t = S.textures[tex];
+    bool direct = true;  // t is the material's own texture
     for (int guard = 0; (FEAT & FEAT_TEX_CHECKER) && guard < 8 && t.kind == MLRT_TEX_CHECKER; guard++) {  // textures.rs:40-49
         const real sines = sin_r((real)5 * p.x) * sin_r((real)5 * p.y) * sin_r((real)5 * p.z);
         t = S.textures[sines < (real)0 ? t.a : t.b];
+        direct = false;
     }
     if (t.kind == MLRT_TEX_SOLID) return ld3(t.color);
     if ((FEAT & FEAT_TEX_NOISE) && t.kind == MLRT_TEX_NOISE) {  // textures.rs:163-167
-        const real x = (real)1 + sin_r(t.scale * p.z + (real)10 * perlin_turbulence(S, t.a, t.scale * p));
+#ifdef MLRT_PROBE_NO_NOISE  // cost probe (experiments only): what the Perlin code costs a shading batch
+        return mk((real)0.5, (real)0.5, (real)0.5);
+#endif
+        // (have_turbulence: only for a NoiseTexture that is the material's own texture, not one behind a Checker)
+        const real turb = (have_turbulence && direct) ? turbulence : perlin_turbulence(S, t.a, t.scale * p);
+        const real x = (real)1 + sin_r(t.scale * p.z + (real)10 * turb);
         return mk((real)0.5 * x, (real)0.5 * x, (real)0.5 * x);
     }
     if ((FEAT & FEAT_TEX_IMAGE) && t.kind == MLRT_TEX_IMAGE) {  // image_texture.rs:16-28
@@ -609,10 +641,19 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
     }
 }
 
-// Evaluate the closest hit the cursor found and the material response.  Returns true when the path continues with
-// (o, d) replaced and `thr` multiplied by the attenuation; false when it ends with radiance `emitted`.
+// Shading in two halves.  hit_attributes: the closest hit the cursor found (point, normal, uv, material).  scatter: the
+// material response; returns true when the path continues with (o, d) replaced and `thr` multiplied by the attenuation,
+// false when it ends with radiance `emitted`.  Between the two the batch evaluates, for the whole wave at once, what a
+// few of its lanes need and is long (wave_turbulence).
+struct HitAttr {
+    P3 p;
+    V3 normal;
+    real u, v;
+    bool front_face;
+    DMaterial<real> m;
+};
 template <uint32_t FEAT>
-DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key, int bounce) {
+DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
     const DNode<real> n = S.nodes[c.hit_node];
     const int kind = n.tag & TAG_KIND_MASK;
     P3 p;
@@ -661,8 +702,21 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
             }
         }
     }
+    HitAttr h;
+    h.p = p; h.normal = normal; h.u = u; h.v = v; h.front_face = front_face;
+    h.m = S.materials[mat_id];
+    return h;
+}
+// `turbulence`: the NoiseTexture turbulence of the hit point when the batch has already evaluated it (have_turbulence).
+template <uint32_t FEAT>
+DEV bool scatter(const Scene& S, const HitAttr& h, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key, int bounce, bool have_turbulence, real turbulence) {
+    const P3 p = h.p;
+    const V3 normal = h.normal;
+    const real u = h.u, v = h.v;
+    const bool front_face = h.front_face;
+    const DMaterial<real> m = h.m;
+    const V3 dw = to_v3(d);  // world direction in shading precision
     const V3 pf = to_v3(p);
-    const DMaterial<real> m = S.materials[mat_id];
     const int mk_kind = m.kind & 0xFF;
     // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
     // volumes.rs:79) and Dielectric may draw one word: the scatter's block, evaluated once for the whole batch.
@@ -676,7 +730,7 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
         V3 dir = normal + s;
         const real eps = (real)1e-8;
         if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
-        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);
         o = p; d = to_p3(dir);
         return true;
     }
@@ -709,11 +763,11 @@ DEV bool shade(const Scene& S, const Cursor& c, P3& o, P3& d, V3& thr, V3& emitt
     }
     if ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
         const V3 dir = s;
-        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);
+        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);
         o = p; d = to_p3(dir);
         return true;
     }
-    emitted = texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf);  // DiffuseLight, materials.rs:119-127
+    emitted = texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);  // DiffuseLight, materials.rs:119-127
     return false;
 }
 
@@ -1014,15 +1068,40 @@ void mlrt_render_kernel(const KParams<real> P) {
             const bool mine = phase == PH_SHADE;
             bool new_ray = false;
             bool freed = false;  // this lane flushed a bank: starved lanes may try again
+            // hit attributes first, then - wave-uniform - the turbulence of the few lanes that hit a NoiseTexture
+            const bool hit = mine && has_path && c.hit_node >= 0;
+            constexpr bool kWaveNoise = (FEAT & FEAT_TEX_NOISE) && kFast;
+            HitAttr h;
+            bool have_turbulence = false;
+            real turbulence = (real)0;
+            if (kWaveNoise) {
+                if (hit) h = hit_attributes<FEAT>(S, c, o, d);
+                bool marble = false;
+                int table = 0;
+                float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+                if (hit && (h.m.kind & MATFLAG_NOISE)) {
+                    const DTexture<real> t = S.textures[h.m.tex];
+                    marble = true; table = t.a;
+                    qx = (float)t.scale * (float)h.p.x; qy = (float)t.scale * (float)h.p.y; qz = (float)t.scale * (float)h.p.z;  // scale * p, textures.rs:164
+                }
+                for (unsigned long long pending = __ballot(marble); pending != 0ull; pending &= pending - 1ull) {
+                    const int src = (int)__builtin_ctzll(pending);
+                    const float value = wave_turbulence(S, __builtin_amdgcn_readlane(table, src), __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qx), src)),
+                                                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qy), src)),
+                                                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qz), src)), lane);
+                    if (lane == src) { turbulence = (real)value; have_turbulence = true; }
+                }
+            }
             if (mine && has_path) {
                 if (MLRT_DEBUG_ON(P) && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
                     printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
                            c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
                 V3 radiance = mk(0, 0, 0);
                 bool done = true;
-                if (c.hit_node >= 0) {
+                if (hit) {
+                    if (!kWaveNoise) h = hit_attributes<FEAT>(S, c, o, d);
                     V3 emitted = mk(0, 0, 0);
-                    if (shade<FEAT>(S, c, o, d, thr, emitted, g, key, P.max_depth - depth)) {
+                    if (scatter<FEAT>(S, h, o, d, thr, emitted, g, key, P.max_depth - depth, have_turbulence, turbulence)) {
                         depth--;
                         if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
                     } else {
