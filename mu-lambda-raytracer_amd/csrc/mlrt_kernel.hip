@@ -7,25 +7,27 @@
 //
 // What it replaces (reference file:line):
 //   Renderer::render / render_line / render_pixel   raytrace.rs:162-198   -> tile queue + per-lane path regeneration
-//   Camera::get_ray                                 camera.rs:40-48       -> gen_camera_ray
+//   Camera::get_ray                                 camera.rs:40-48       -> gen_camera_ray (f64)
 //   RecursiveRayTracer::trace_internal              raytrace.rs:79-102    -> iterative throughput loop
-//   HittableList::hit                               hittable.rs:53-69     -> world_hit (objects in list order)
-//   BHV::hit / Node::hit / AABB::hit                bhv.rs:29-42,147-165  -> threaded (stackless) BVH walk + slab test
+//   HittableList::hit                               hittable.rs:53-69     -> the order of the linear entry array
+//   BHV::hit / Node::hit / AABB::hit                bhv.rs:29-42,147-165  -> threaded (stackless) BVH walk + slab_hit
 //   Sphere::hit / sphere_uv                         shapes.rs:44-82       -> sphere_hit / sphere_uv
 //   AARect::hit, Block::hit                         aarects.rs:45-64, shapes.rs:172-192 -> rect_hit, box_hit
-//   Translate::hit / Rotate::hit                    transforms.rs:31-42,127-142 -> to_object / from_object
-//   ConstantMedium::hit, Isotropic                  volumes.rs:26-83      -> medium_hit, scatter
-//   Lambertian / Metal / Dielectric / DiffuseLight  materials.rs          -> scatter
+//   Translate::hit / Rotate::hit                    transforms.rs:31-42,127-142 -> to_object / rotate_fwd
+//   ConstantMedium::hit, Isotropic                  volumes.rs:26-83      -> special_entry (MEDIUM), scatter
+//   Lambertian / Metal / Dielectric / DiffuseLight  materials.rs          -> hit_attributes, scatter
 //   SolidColor / Checker / Perlin / Image           textures.rs, image_texture.rs -> texture_value
-//   to_rgb                                          raytrace.rs:59-68     -> fused tile epilogue
+//   to_rgb                                          raytrace.rs:59-68     -> mlrt_resolve_kernel
 //   Rngator (Pcg64 per row)                         rngator.rs:27-31      -> Philox4x32-10 per (pixel, sample)
 //
 // Execution model: persistent workgroups.  Each workgroup stages the packed scene blob into LDS once
-// (16-byte coalesced loads), then each WAVE pulls tiles (pix_per_tile consecutive pixels of a row) from a global
-// atomic counter.  Inside a tile the pix*spp samples form one queue; a lane whose path has ended takes the next
-// queue entry immediately (__ballot + mbcnt prefix), so lanes stay busy until the tile is exhausted.  Finished
-// samples are added to per-wave pixel accumulators in LDS as 64-bit fixed point (2^-32): integer adds are
-// associative, so the image is bit-identical however samples are distributed over lanes, waves or GPUs.
+// (16-byte coalesced loads), then each WAVE pulls tiles (a pixel group x a chunk of its samples) from the frame's
+// queue (interleaved sub-queues, chunk-major tapering passes: see KParams).  Inside a tile the samples form one
+// queue; a lane whose path has ended takes the next entry in the next shading batch (__ballot + mbcnt prefix),
+// and a wave keeps several tiles open so that no lane waits for a tile's last path.  Finished samples are added
+// to per-tile accumulators in LDS as 64-bit fixed point (2^-32), finished tiles to the frame buffer in HBM:
+// integer adds are associative, so the image is bit-identical however samples are distributed over lanes,
+// waves or GPUs.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
