@@ -846,44 +846,35 @@ DEV void pin_entry(const DNode<real>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
-// Primary rays of a pixel group (1-4 neighbouring pixels; pinhole camera, for a thin lens see below) all lie inside the pyramid from the camera
-// origin through the group's footprint on the image plane, so they can only hit the spheres that touch that pyramid:
-// typically the ground and one or two others.  A pre-pass (one thread per pixel group, once per frame) scans the entry
-// array (sphere against the four side planes, outward margins) and leaves the touching sphere entries, in entry order,
-// in a 32-byte record: u16 count (kCandInvalid when more than kCand touch: that group's samples walk the BVH as usual),
-// the entry indices, and the group's image row.  A wave opening a tile copies the record into the tile's bank, and a fresh sample tests
-// exactly those entries instead of walking the BVH (43 % of all traversal steps of `random` are primary-ray steps).
-// The closest hit is the one the walk finds: the walk visits sphere entries in the same order, the list is a superset
-// of the spheres any of the group's rays can hit, and Sphere::hit does not depend on what was tested before it except
-// through closest-so-far.
-constexpr int kCandRecord = 16;  // u16 per record: count + kCand entries + pad
-__global__ void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* records) {
-    const int group = blockIdx.x * blockDim.x + threadIdx.x;
-    if (group >= P.n_groups) return;
+// Primary rays of a pixel group (1-4 neighbouring pixels; pinhole camera, for a thin lens see below) all lie inside the
+// pyramid from the camera origin through the group's footprint on the image plane, so they can only hit the spheres
+// that touch that pyramid: typically the ground and one or two others.  A pre-pass, once per frame, tests the sphere
+// entries against the four side planes (outward margins) and leaves the touching ones, in entry order, in a 32-byte
+// record per group: u16 count (kCandInvalid when more than kCand touch: that group's samples walk the BVH as usual), the
+// entry indices, and the group's image row.  A wave opening a tile copies the record into the tile's bank, and a fresh
+// sample tests exactly those entries instead of walking the BVH (43 % of all traversal steps of `random` are
+// primary-ray steps).  The closest hit is the one the walk finds: the walk visits sphere entries in the same order, the
+// list is a superset of the spheres any of the group's rays can hit, and Sphere::hit does not depend on what was tested
+// before it except through closest-so-far (GPU test: the image equals the one rendered with MLRT_NO_PRIMARY_LISTS).
+constexpr int kCandRecord = 16;  // u16 per record: count + kCand entries + row
+constexpr int kCoarseMax = 256;
+// Two levels, one wave per 64 consecutive pixel groups of a row: the wave first scans the entry array against the
+// pyramid of the whole 64-group span (64 entries per round, survivors compacted into LDS in entry order: typically 10-30),
+// then every lane tests only those against its own group's pyramid.  (A flat scan of all entries per group cost 0.5 ms per
+// C2 frame.)  A span with more than kCoarseMax survivors falls back to the flat scan.
+__global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* records) {
+    __shared__ uint16_t coarse[kCoarseMax];
+    const int lane = threadIdx.x;
     const DNode<real>* nodes = reinterpret_cast<const DNode<real>*>(P.blob + P.off_nodes);
-    const int row_k = group / P.tiles_per_row;
-    const int x0 = (group - row_k * P.tiles_per_row) * P.pix_per_tile;
-    const int npix = min(P.pix_per_tile, P.width - x0);
+    const int spans_per_row = (P.tiles_per_row + 63) >> 6;
+    const int row_k = (int)blockIdx.x / spans_per_row;
+    const int gx0 = ((int)blockIdx.x - row_k * spans_per_row) << 6;
+    const int gx = gx0 + lane;
     const int j = P.rows ? P.rows[row_k] : row_k;
-    // footprint in the (s, t) coordinates of Camera::get_ray, 1/100 pixel wider on every side
     const double inv_w = 1.0 / ((double)P.width - 1.0), inv_h = 1.0 / ((double)P.height - 1.0);
-    const double s0 = ((double)x0 - 0.01) * inv_w, s1 = ((double)(x0 + npix) + 0.01) * inv_w;
-    const double t0 = ((double)j - 0.01) * inv_h, t1 = ((double)j + 1.01) * inv_h;
     const P3 org = ld3p(P.cam_origin);
     const P3 base = ld3p(P.cam_llc) - org;
     const P3 hor = ld3p(P.cam_horizontal), ver = ld3p(P.cam_vertical);
-    auto corner = [&](double s, double t) {
-        const P3 q = base + s * hor + t * ver;
-        return mk((real)q.x, (real)q.y, (real)q.z);
-    };
-    const V3 d00 = corner(s0, t0), d10 = corner(s1, t0), d01 = corner(s0, t1), d11 = corner(s1, t1);
-    const V3 mid = d00 + d11;
-    auto plane = [&](V3 a, V3 b) {  // unit normal of the plane through the origin, a and b, pointing to the inside
-        V3 nrm = mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-        nrm = unit(nrm);
-        return dot(nrm, mid) < (real)0 ? -nrm : nrm;
-    };
-    const V3 n_left = plane(d00, d01), n_right = plane(d10, d11), n_bottom = plane(d00, d10), n_top = plane(d01, d11);
     const V3 of = mk((real)org.x, (real)org.y, (real)org.z);
     // Thin lens (camera.rs:41-47): a ray leaves origin + delta, |delta| <= lens_radius, towards the point its pinhole twin hits
     // on the focus plane, so at distance t it is |delta| * |1 - t / f| away from that twin, f >= focus_dist the twin's distance
@@ -891,25 +882,67 @@ __global__ void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* recor
     const P3 fw = mkp(-base.x - 0.5 * hor.x - 0.5 * ver.x, -base.y - 0.5 * hor.y - 0.5 * ver.y, -base.z - 0.5 * hor.z - 0.5 * ver.z);  // focus_dist * w
     const real lens = (real)(P.lens_radius * 1.001);
     const real inv_focus = P.has_lens ? (real)(1.0 / sqrt(fw.x * fw.x + fw.y * fw.y + fw.z * fw.z)) : (real)0;
+    // the four side planes (inward unit normals through the camera origin) of the pyramid over pixels [xa, xb) of row j,
+    // footprint in the (s, t) coordinates of Camera::get_ray, 1/100 pixel wider on every side
+    struct Pyramid { V3 left, right, bottom, top; };
+    auto pyramid = [&](int xa, int xb) {
+        const double s0 = ((double)xa - 0.01) * inv_w, s1 = ((double)xb + 0.01) * inv_w;
+        const double t0 = ((double)j - 0.01) * inv_h, t1 = ((double)j + 1.01) * inv_h;
+        auto corner = [&](double s, double t) {
+            const P3 q = base + s * hor + t * ver;
+            return mk((real)q.x, (real)q.y, (real)q.z);
+        };
+        const V3 d00 = corner(s0, t0), d10 = corner(s1, t0), d01 = corner(s0, t1), d11 = corner(s1, t1);
+        const V3 mid = d00 + d11;
+        auto plane = [&](V3 a, V3 b) {
+            V3 nrm = mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+            nrm = unit(nrm);
+            return dot(nrm, mid) < (real)0 ? -nrm : nrm;
+        };
+        Pyramid py;
+        py.left = plane(d00, d01); py.right = plane(d10, d11); py.bottom = plane(d00, d10); py.top = plane(d01, d11);
+        return py;
+    };
+    auto touches = [&](const Pyramid& py, const DNode<real>& q) {
+        if ((q.tag & TAG_KIND_MASK) != TAG_SPHERE) return false;
+        const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
+        const real far = abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z);  // >= |cc|
+        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * far + lens * max_r((real)1, (far + abs_r(q.v[3])) * inv_focus);
+        return dot(py.left, cc) >= -reach && dot(py.right, cc) >= -reach && dot(py.bottom, cc) >= -reach && dot(py.top, cc) >= -reach;
+    };
+    // level 1: the span's survivors, in entry order
+    const Pyramid span = pyramid(gx0 * P.pix_per_tile, min(P.width, (gx0 + 64) * P.pix_per_tile));
+    int n_coarse = 0;  // wave-uniform
+    for (int e0 = 0; e0 < P.n_nodes; e0 += 64) {
+        const int e = e0 + lane;
+        const bool in = e < P.n_nodes && touches(span, nodes[e < P.n_nodes ? e : 0]);
+        const unsigned long long mask = __ballot(in);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        if (in && n_coarse + rank < kCoarseMax) coarse[n_coarse + rank] = (uint16_t)e;
+        n_coarse += (int)__popcll(mask);
+    }
+    __syncthreads();
+    const bool flat = n_coarse > kCoarseMax;
+    const int n_candidates = flat ? P.n_nodes : n_coarse;
+    // level 2: the lane's own pixel group
+    if (gx >= P.tiles_per_row) return;
+    const int x0 = gx * P.pix_per_tile;
+    const Pyramid own = pyramid(x0, min(P.width, x0 + P.pix_per_tile));
     uint16_t list[kCandRecord];
 #pragma unroll
     for (int k = 0; k < kCandRecord; k++) list[k] = 0;
     int count = 0;
-    for (int e = 0; e < P.n_nodes; e++) {  // e is uniform: the entry is read once per wave
-        const DNode<real> q = nodes[e];
-        if ((q.tag & TAG_KIND_MASK) != TAG_SPHERE) continue;
-        const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
-        const real far = abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z);  // >= |cc|
-        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * far + lens * max_r((real)1, (far + abs_r(q.v[3])) * inv_focus);
-        if (dot(n_left, cc) >= -reach && dot(n_right, cc) >= -reach && dot(n_bottom, cc) >= -reach && dot(n_top, cc) >= -reach) {
+    for (int k = 0; k < n_candidates; k++) {
+        const int e = flat ? k : (int)coarse[k];
+        if (touches(own, nodes[e])) {
 #pragma unroll
-            for (int k = 0; k < kCand; k++) if (k == count) list[1 + k] = (uint16_t)e;
+            for (int m = 0; m < kCand; m++) if (m == count) list[1 + m] = (uint16_t)e;
             count++;
         }
     }
     list[0] = (uint16_t)(count <= kCand ? count : kCandInvalid);
     list[kCandRecord - 1] = (uint16_t)j;  // the group's image row rides along (image height < 65536)
-    uint32_t* out = reinterpret_cast<uint32_t*>(records + (size_t)group * kCandRecord);
+    uint32_t* out = reinterpret_cast<uint32_t*>(records + ((size_t)row_k * P.tiles_per_row + gx) * kCandRecord);
 #pragma unroll
     for (int k = 0; k < kCandRecord / 2; k++) out[k] = (uint32_t)list[2 * k] | ((uint32_t)list[2 * k + 1] << 16);
 }
@@ -1287,7 +1320,7 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
     const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
     int rc;
     if (P.primary_lists) {
-        hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel, dim3((unsigned)((P.n_groups + 255) / 256)), dim3(256), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
+        hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel, dim3((unsigned)(P.n_rows * ((P.tiles_per_row + 63) / 64))), dim3(64), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
         rc = (int)hipGetLastError();
         if (rc != 0) return rc;
     }

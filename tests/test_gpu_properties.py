@@ -237,3 +237,24 @@ def test_movie_mode_equals_one_process_per_frame(mlrt, tmp_path):
                              check=True, capture_output=True, text=True).stdout
         assert open(prefix + "%04d.ppm" % i).read() == one, i
         theta += 0.5 * pi / 180
+
+
+@pytest.mark.parametrize("aperture", [0.0, 0.1, 0.6])
+def test_primary_candidate_lists_do_not_change_the_image(mlrt, monkeypatch, aperture):
+    """Sphere-only scenes: a pixel group's primary rays test the spheres that touch the group's pyramid (a per-frame
+    pre-pass; for a thin lens the pyramid is widened by the lens) instead of walking the BVH.  The closest hits - and so
+    the image - must be exactly those of the walk (MLRT_NO_PRIMARY_LISTS), for every pixel of a frame that has spheres at
+    all depths, with and without defocus."""
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5, aperture, 10.0 if aperture else None)
+    params = mlrt.make_params(w, 300, 200, 24)
+    r = mlrt.Renderer(w, cam, params)
+    with_lists = r.render()
+    r.close()
+    monkeypatch.setenv("MLRT_NO_PRIMARY_LISTS", "1")
+    r = mlrt.Renderer(w, cam, params)
+    walked = r.render()
+    r.close()
+    monkeypatch.delenv("MLRT_NO_PRIMARY_LISTS")
+    assert np.array_equal(with_lists, walked)
+    w.close()
