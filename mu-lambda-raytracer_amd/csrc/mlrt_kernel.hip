@@ -1042,6 +1042,26 @@ void mlrt_render_kernel(const KParams<real> P) {
     c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
     c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
 
+    // Tiles whose last sample has finished: the WAVE looks at the banks' counts once per shading batch (one LDS read for
+    // all banks; LDS operations of a wave execute in order, so every add of a tile is visible when its count reads zero)
+    // and flushes finished tiles into the frame buffer - integer atomics, so the frame is bit-identical however pixels'
+    // samples were split into tiles and whichever wave / GPU rendered them.  (Before, every finishing lane waited for
+    // the value its atomic decrement returned, and the flush loop sat in the divergent per-lane code.)
+    unsigned int open_banks = 0u;  // wave-uniform: banks holding a tile that is not flushed yet
+    auto flush_finished_banks = [&]() -> bool {
+        const int remaining = lane < n_banks ? bank_remaining[lane] : 1;
+        unsigned int finished = (unsigned int)__ballot(remaining == 0) & open_banks;
+        if (finished == 0u) return false;
+        open_banks &= ~finished;
+        for (; finished != 0u; finished &= finished - 1u) {
+            const int bank = (int)__builtin_ctz(finished);
+            const int n_values = __builtin_amdgcn_readfirstlane(bank_values[bank]);
+            const int out0 = __builtin_amdgcn_readfirstlane(bank_out[bank]);
+            if (lane < n_values) atomicAdd(&P.acc_global[(size_t)out0 + lane], acc[bank * bank_vals + lane]);
+        }
+        return true;
+    };
+
     DNode<real> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
     for (;;) {
         // (A) one traversal step
@@ -1102,7 +1122,6 @@ void mlrt_render_kernel(const KParams<real> P) {
             if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
             const bool mine = phase == PH_SHADE;
             bool new_ray = false;
-            bool freed = false;  // this lane flushed a bank: starved lanes may try again
             // hit attributes first, then - wave-uniform - the turbulence of the few lanes that hit a NoiseTexture
             const bool hit = mine && has_path && c.hit_node >= 0;
             constexpr bool kWaveNoise = (FEAT & FEAT_TEX_NOISE) && kFast;
@@ -1151,20 +1170,11 @@ void mlrt_render_kernel(const KParams<real> P) {
                     atomicAdd(&acc[sum0 + 1], to_fixed(radiance.y));
                     atomicAdd(&acc[sum0 + 2], to_fixed(radiance.z));
                     has_path = false;
-                    // the lane that finishes the last sample of a tile flushes that tile's sums into the frame buffer:
-                    // integer atomics, so the frame is bit-identical however pixels' samples were split into tiles and
-                    // whichever wave / GPU rendered them (LDS operations of a wave execute in order, so every add of
-                    // the tile is visible to the lane that sees the count reach zero)
-                    const int bank = pix >> kPixBankShift;
-                    if (atomicSub(&bank_remaining[bank], 1) == 1) {
-                        const int n_values = bank_values[bank];
-                        const int out0 = bank_out[bank];
-                        for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * bank_vals + i]);
-                        freed = true;
-                    }
+                    atomicSub(&bank_remaining[pix >> kPixBankShift], 1);  // (no return value: the wave looks at the counts below)
                 }
             }
-            if (__ballot(freed) != 0ull && phase == PH_WAIT) phase = PH_SHADE;  // they join the next shading batch
+            const bool freed = flush_finished_banks();
+            if (freed && phase == PH_WAIT) phase = PH_SHADE;  // starved lanes join the next shading batch
             // Path regeneration, in wave-uniform control flow so the tile state stays uniform: the batch's lanes without
             // a path take the next queue entries in lane order, opening the next tile when the current one runs out.
             bool want = mine && !has_path;
@@ -1175,13 +1185,15 @@ void mlrt_render_kernel(const KParams<real> P) {
                     // open the next tile into ANY bank whose previous tile has fully drained (not the next of a ring: one
                     // 50-bounce path would hold its bank, and with it the whole ring, while the other lanes run out of samples)
                     if (queue_done) break;
-                    const unsigned long long free_banks = __ballot(lane < n_banks && bank_remaining[lane < n_banks ? lane : 0] == 0);
-                    if (free_banks == 0ull) break;
+                    if (P.max_depth == 0) flush_finished_banks();  // (samples that end inside this loop)
+                    const unsigned int free_banks = ~open_banks & (n_banks >= 32 ? 0xFFFFFFFFu : (1u << n_banks) - 1u);
+                    if (free_banks == 0u) break;
                     // (LDS / global loads below are wave-uniform by construction; readfirstlane tells the compiler, which
                     // keeps the tile state in scalar registers)
-                    const int nb = (int)__builtin_ctzll(free_banks);
+                    const int nb = (int)__builtin_ctz(free_banks);
                     const int tile = queue_pop();
                     if (tile >= P.n_tiles) { queue_done = true; break; }
+                    open_banks |= 1u << nb;
                     // tile -> (pass, pixel group): chunk-major queue, see KParams
                     const int pass = magic_div(tile, P.n_groups_magic, P.n_groups_shift);
                     const int group = tile - pass * P.n_groups;
@@ -1230,12 +1242,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                     want = false;
                     if (!new_ray) {  // max_depth == 0: the sample contributes 0 (raytrace.rs:87-89)
                         has_path = false;
-                        const int bank = t_bank;
-                        if (atomicSub(&bank_remaining[bank], 1) == 1) {
-                            const int n_values = bank_values[bank];
-                            const int out0 = bank_out[bank];
-                            for (int i = 0; i < n_values; i++) atomicAdd(&P.acc_global[(size_t)out0 + i], acc[bank * bank_vals + i]);
-                        }
+                        atomicSub(&bank_remaining[t_bank], 1);
                     }
                 }
                 t_next += min((int)__popcll(need), avail);
@@ -1265,6 +1272,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_shade += t - st_c0; }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
     }
+    flush_finished_banks();  // (max_depth == 0 finishes its last samples inside the regeneration loop)
     if (MLRT_STATS_ON(P) && lane == 0) {
         atomicAdd(&P.stats[0], (unsigned long long)st_iter); atomicAdd(&P.stats[1], (unsigned long long)st_steps);
         atomicAdd(&P.stats[2], (unsigned long long)st_sb); atomicAdd(&P.stats[3], (unsigned long long)st_sl);
