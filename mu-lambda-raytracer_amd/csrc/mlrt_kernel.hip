@@ -177,8 +177,13 @@ struct RngKey {
 };
 DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0, uint32_t& o1,
                        uint32_t& o2, uint32_t& o3) {
+#ifdef MLRT_PROBE_PHILOX_ROUNDS  // cost probe (experiments only): 20 rounds instead of 10 cost C2 +10 %: that is Philox's share
+    constexpr int kRounds = MLRT_PROBE_PHILOX_ROUNDS;
+#else
+    constexpr int kRounds = 10;
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < kRounds; r++) {
         // one 32x32->64 multiply (v_mad_u64_u32) yields both halves: integer multiplies are quarter rate on CDNA
         const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
@@ -591,9 +596,6 @@ DEV V3 texture_value(const Scene& S, int tex, V3 solid, real u, real v, V3 p, bo
     }
     if (t.kind == MLRT_TEX_SOLID) return ld3(t.color);
     if ((FEAT & FEAT_TEX_NOISE) && t.kind == MLRT_TEX_NOISE) {  // textures.rs:163-167
-#ifdef MLRT_PROBE_NO_NOISE  // cost probe (experiments only): what the Perlin code costs a shading batch
-        return mk((real)0.5, (real)0.5, (real)0.5);
-#endif
         // (have_turbulence: only for a NoiseTexture that is the material's own texture, not one behind a Checker)
         const real turb = (have_turbulence && direct) ? turbulence : perlin_turbulence(S, t.a, t.scale * p);
         const real x = (real)1 + sin_r(t.scale * p.z + (real)10 * turb);
@@ -1030,6 +1032,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     };
     unsigned int st_psteps = 0, st_pspecial = 0;  // MLRT_STATS: traversal steps / special entries of primary rays
     unsigned long long st_c_trav = 0, st_c_special = 0, st_c_shade = 0, st_c0 = 0;  // MLRT_STATS: shader clocks per loop section
+    unsigned long long st_c_end = 0, st_c_regen = 0, st_c1 = 0;  // MLRT_STATS: within the shading batch: paths ended/scattered, regeneration (the rest: new-ray setup)
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
     int phase = PH_SHADE;  // every lane starts by asking for a sample
@@ -1174,6 +1177,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                 }
             }
             const bool freed = flush_finished_banks();
+            if (MLRT_STATS_ON(P)) { st_c1 = __builtin_readcyclecounter(); st_c_end += st_c1 - st_c0; }
             if (freed && phase == PH_WAIT) phase = PH_SHADE;  // starved lanes join the next shading batch
             // Path regeneration, in wave-uniform control flow so the tile state stays uniform: the batch's lanes without
             // a path take the next queue entries in lane order, opening the next tile when the current one runs out.
@@ -1247,6 +1251,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                 }
                 t_next += min((int)__popcll(need), avail);
             }
+            if (MLRT_STATS_ON(P)) st_c_regen += __builtin_readcyclecounter() - st_c1;
             if (mine) {
                 if (new_ray) {
                     c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
@@ -1280,6 +1285,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         atomicAdd(&P.stats[6], (unsigned long long)st_samples); atomicAdd(&P.stats[7], (unsigned long long)st_tiles);
         atomicAdd(&P.stats[11], (unsigned long long)st_psteps); atomicAdd(&P.stats[12], (unsigned long long)st_pspecial);
         atomicAdd(&P.stats[8], st_c_trav); atomicAdd(&P.stats[9], st_c_special); atomicAdd(&P.stats[10], st_c_shade);
+        atomicAdd(&P.stats[13], st_c_end); atomicAdd(&P.stats[14], st_c_regen);
     }
 }
 
