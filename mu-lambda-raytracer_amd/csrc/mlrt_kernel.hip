@@ -831,11 +831,20 @@ DEV unsigned long long to_fixed(float c) {
 #ifndef MLRT_BOX_SPECIAL
 #define MLRT_BOX_SPECIAL 0
 #endif
+// Batch thresholds (lanes parked on special entries / on shading before the batch runs), per variant: measured optima
+// (A/B in one process): sphere-only variant 24 / 40 (C2: 45.1 ms at 32 / 32, 43.7 at 24 / 40: its special batch is short,
+// its shading batch long), full variant 32 / 32 (final_scene: 24 / 32 -1.5 %, 32 / 40 and 40 / 32 -5 %).
 #ifndef MLRT_T_SPECIAL
 #define MLRT_T_SPECIAL 32
 #endif
 #ifndef MLRT_T_SHADE
 #define MLRT_T_SHADE 32
+#endif
+#ifndef MLRT_T_SPECIAL_LEAN
+#define MLRT_T_SPECIAL_LEAN 24
+#endif
+#ifndef MLRT_T_SHADE_LEAN
+#define MLRT_T_SHADE_LEAN 40
 #endif
 enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  // WAIT: no sample to be had until a bank of the ring drains
 
@@ -1103,7 +1112,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
-        if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= MLRT_T_SPECIAL || m_trav == 0ull))) {
+        if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= (FEAT == 0 ? MLRT_T_SPECIAL_LEAN : MLRT_T_SPECIAL) || m_trav == 0ull))) {
             if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
             if (phase == PH_SPECIAL) {
                 special_entry<FEAT>(S, n, c, o, d, g, key);
@@ -1120,7 +1129,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_special += t - st_c0; st_c0 = t; }
         // (C) batched shading, path termination and regeneration
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
-        const bool batch = m_shade != 0ull && (__popcll(m_shade) >= MLRT_T_SHADE || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
+        const bool batch = m_shade != 0ull && (__popcll(m_shade) >= (FEAT == 0 ? MLRT_T_SHADE_LEAN : MLRT_T_SHADE) || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
         if (MLRT_RARELY(batch)) {
             if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
             const bool mine = phase == PH_SHADE;
