@@ -157,7 +157,11 @@ typedef struct mlrt_camera { /* the private fields of src/camera.rs:3-12, as Cam
 typedef struct mlrt_params {
     int32_t image_width, image_height, samples_per_pixel; /* RenderingParams, raytrace.rs:50-55 */
     int32_t max_depth;                                    /* RecursiveRayTracer, raytrace.rs:74-76 */
-    uint64_t seed;                                        /* SeedableRngator, rngator.rs:17-31 */
+    uint64_t seed;                                        /* SeedableRngator, rngator.rs:17-31.  The device does not replay the
+                                                           * reference's per-row Pcg64 streams (a row's stream is consumed pixel by
+                                                           * pixel: inherently serial): every (pixel, sample) owns a Philox4x32-10
+                                                           * stream keyed by this seed - same distributions, image deterministic and
+                                                           * independent of how rows are spread over GPUs ("RNG contract") */
     int32_t background_kind;                              /* MLRT_BG_* */
     int32_t _pad;
     double background_top[3], background_bottom[3]; /* GradientBackground, raytrace.rs:12-35 */
