@@ -170,7 +170,7 @@ DEV V3 unit(V3 a) {
 // with ONE refill site: the draw order is unchanged, only the number of divergent refill branches drops.
 struct Rng {
     uint32_t pixel, sample, draw;
-    uint32_t b0, b1, b2, b3;
+    uint32_t b3;  // word 3 of the block `draw` is in (valid when draw % 4 == 3): all that is kept of a block between draws
 };
 struct RngKey {
     uint32_t k0, k1;
@@ -194,19 +194,20 @@ DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-DEV void rng_fill(Rng& g, RngKey key, uint32_t block) {
-    philox4x32_10(key.k0, key.k1, block, g.sample, g.pixel, 0u, g.b0, g.b1, g.b2, g.b3);
-#ifdef MLRT_PROBE_PHILOX  // sensitivity probe (experiments only): the Philox arithmetic twice, result unchanged
-    uint32_t x0, x1, x2, x3;
-    philox4x32_10(key.k0, key.k1, block + 1u, g.sample, g.pixel, 0u, x0, x1, x2, x3);
-    if (g.pixel == 0xFFFFFFFFu) { g.b0 ^= x0; g.b1 ^= x1; g.b2 ^= x2; g.b3 ^= x3; }
-#endif
-}
+// One draw of the stream outside a scatter (a ConstantMedium's, during traversal).  Word 3 of a block is served from the
+// lane's state - after a scatter that is the usual case - any other word evaluates its block (a second medium draw in one
+// ray segment is rare: keeping all four words cost three registers in the variant whose shading batch is short of them).
 DEV uint32_t rng_next(Rng& g, RngKey key) {
     const uint32_t i = g.draw & 3u;
-    if (i == 0) rng_fill(g, key, g.draw >> 2);
+    uint32_t w = g.b3;
+    if (i != 3u) {
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10(key.k0, key.k1, g.draw >> 2, g.sample, g.pixel, 0u, w0, w1, w2, w3);
+        g.b3 = w3;
+        w = i == 0 ? w0 : (i == 1 ? w1 : w2);
+    }
     g.draw++;
-    return i == 0 ? g.b0 : (i == 1 ? g.b1 : (i == 2 ? g.b2 : g.b3));
+    return w;
 }
 // The words of one Material::scatter.  Contract (mirrored by the oracle's PhiloxStream::begin_scatter/end_scatter): a
 // scatter starts on a block boundary and owns words 0-2 of its block, whatever the material draws from them (Lambertian /
@@ -788,15 +789,16 @@ DEV V3 background_color(const KParams<real>& P, const FrameParams& F, P3 d) {  /
 // inverse CDF from two words (r = sqrt(u1'), phi = 2*pi*u2; the reference's rejection loop is vec.rs:45-52, quirk Q6:
 // the draws are consumed even when lens_radius == 0) - are exactly Philox block 0: no loop, no refill branch.
 DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
-    rng_fill(g, key, 0u);
+    uint32_t b0, b1, b2, b3;
+    philox4x32_10(key.k0, key.k1, 0u, g.sample, g.pixel, 0u, b0, b1, b2, b3);
     g.draw = 4u;
     // (fast build: times the reciprocal - an f64 division is ~25 instructions, twice per sample)
-    const double s = kFast ? ((double)i + u01d(g.b0)) * F.inv_wm1 : ((double)i + u01d(g.b0)) / ((double)P.width - 1.0);
-    const double t = kFast ? ((double)j + u01d(g.b1)) * F.inv_hm1 : ((double)j + u01d(g.b1)) / ((double)P.height - 1.0);
+    const double s = kFast ? ((double)i + u01d(b0)) * F.inv_wm1 : ((double)i + u01d(b0)) / ((double)P.width - 1.0);
+    const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : ((double)j + u01d(b1)) / ((double)P.height - 1.0);
     double rdx = 0.0, rdy = 0.0;
     if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
-        const double u1 = ((double)(g.b2 >> 8) + 1.0) * (1.0 / 16777216.0);
-        const double turn = u01d(g.b3);
+        const double u1 = ((double)(b2 >> 8) + 1.0) * (1.0 / 16777216.0);
+        const double turn = u01d(b3);
         double cs, sn;
         if (kFast) { cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
         else { const double phi = 2.0 * 3.14159265358979323846264338327950288 * turn; cs = cos(phi); sn = sin(phi); }
@@ -1049,7 +1051,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     int pix = 0, depth = 0;  // pix: the lane's bank << kPixBankShift | index of its pixel's first sum in acc
     P3 o = mkp(0, 0, 0), d = mkp(0, 0, 1);
     V3 thr = mk(1, 1, 1);
-    Rng g = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    Rng g = {0u, 0u, 0u, 0u};
     Cursor c;
     c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
     c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
