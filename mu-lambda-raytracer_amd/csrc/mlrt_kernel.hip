@@ -30,6 +30,7 @@
 // waves or GPUs.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "../../include/mlrt.h"
@@ -93,6 +94,9 @@ struct FrameParams {
 };
 constexpr int kFrameParamBytes = 224;
 static_assert(sizeof(FrameParams) <= kFrameParamBytes, "FrameParams must fit its LDS slot");
+// the kernel copies cam_origin ... inv_hm1 as 21 consecutive doubles from the argument struct
+static_assert(offsetof(FrameParams, inv_hm1) - offsetof(FrameParams, cam_origin) == 20 * sizeof(double), "FrameParams: camera block layout");
+static_assert(offsetof(mlrt::KParams<MLRT_REAL>, inv_hm1) - offsetof(mlrt::KParams<MLRT_REAL>, cam_origin) == 20 * sizeof(double), "KParams: camera block layout");
 
 // ---------------------------------------------------------------------------------------------- math helpers
 DEV int magic_div(int n, uint32_t magic, int shift) { return shift < 0 ? n : (int)(__umulhi((uint32_t)n, magic) >> shift); }  // KParams: n / divisor
