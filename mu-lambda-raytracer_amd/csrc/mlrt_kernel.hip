@@ -1089,10 +1089,11 @@ void mlrt_render_kernel(const KParams<real> P) {
 #ifndef MLRT_STEPS
 #define MLRT_STEPS 4
 #endif
+        if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
 #pragma unroll
         for (int sub = 0; sub < MLRT_STEPS; sub++) {
         pin_entry(n);
-        if (MLRT_STATS_ON(P)) { st_c0 = __builtin_readcyclecounter(); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth)); }
+        if (MLRT_STATS_ON(P)) { st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth)); }
         // The array ends in a TAG_END sentinel, so there is no bounds test.  Two shapes of the same step (measured): the
         // sphere-only variant runs at 6 waves per SIMD and is bound by vector-instruction issue, where two nested
         // branches cost fewer vector instructions than selects; the full variant (4 waves, box entries resolved in the
@@ -1123,7 +1124,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         }
         n = fetch_entry(S, c.node, n_nodes);
         }
-        if (MLRT_STATS_ON(P)) { st_iter++; st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); const unsigned long long t = __builtin_readcyclecounter(); st_c_trav += t - st_c0; st_c0 = t; }
+        if (MLRT_STATS_ON(P)) { st_iter++; const unsigned long long t = __builtin_readcyclecounter(); st_c_trav += t - st_c0; st_c0 = t; }
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
