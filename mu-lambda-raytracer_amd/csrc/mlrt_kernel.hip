@@ -360,6 +360,27 @@ DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) 
 #endif
     return !(tmax <= tmin);
 }
+// The same decision for the fast build with two instructions less per step: the far bound min(far, closest) * slack is
+// min(far * slack, closest * slack) (rounding is monotone), and closest * slack changes only when a hit is accepted, so
+// the caller passes it in: no min with - and no canonicalisation of - a value the compiler cannot see the origin of.
+DEV bool slab_hit_fast(const DNode<float>& n, const SlabRay& r, float closest_slack) {
+    float t0 = slab_t(n.v[0], r.of.x, r.invd.x), t1 = slab_t(n.v[3], r.of.x, r.invd.x);
+    float tnear = fmaxf(fminf(t0, t1), 0.001f), tfar = fmaxf(t0, t1);
+    t0 = slab_t(n.v[1], r.of.y, r.invd.y); t1 = slab_t(n.v[4], r.of.y, r.invd.y);
+    tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
+    t0 = slab_t(n.v[2], r.of.z, r.invd.z); t1 = slab_t(n.v[5], r.of.z, r.invd.z);
+    tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
+    // (closest_slack and tnear are positive and not NaN - tnear >= 0.001 by the fmaxf above - so the second comparison is done
+    // on the bit patterns: written on floats the compiler folds the two back into one min, canonicalisation included)
+    return !(tfar * 1.0000003f <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
+}
+// closest-so-far as the slab tests of the current build want it
+DEV real slab_far_bound(double closest) { return kFast ? (real)((float)closest * 1.0000003f) : (real)closest; }
+template <typename R>
+DEV bool slab_hit_any(const DNode<R>& n, const SlabRay& r, R far_bound) {
+    if constexpr (sizeof(R) == 4) return slab_hit_fast(n, r, far_bound);
+    else return slab_hit(n, r, (R)0.001, far_bound);
+}
 
 // Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in BOTH builds: with the radius-1000 ground
 // sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
@@ -1090,6 +1111,7 @@ void mlrt_render_kernel(const KParams<real> P) {
 #define MLRT_STEPS 4
 #endif
         if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
+        real far_bound = slab_far_bound(c.closest);  // (hits are accepted in the batches, and by box entries in the full variant's step)
 #pragma unroll
         for (int sub = 0; sub < MLRT_STEPS; sub++) {
         pin_entry(n);
@@ -1100,22 +1122,22 @@ void mlrt_render_kernel(const KParams<real> P) {
         // step) gains 7 % from a branch-free step.
         if (FEAT == 0) {
             if (phase == PH_TRAV) {
-                const int kind = n.tag & TAG_KIND_MASK;
-                if (kind == TAG_INNER) c.node = slab_hit(n, c.sr, (real)0.001, (real)c.closest) ? c.node + 1 : n.link;
-                else phase = kind == TAG_END ? PH_SHADE : PH_SPECIAL;
+                // (inner entries and the sentinel carry no flag bits: the tag is compared whole)
+                if (n.tag == TAG_INNER) c.node = slab_hit_any<real>(n, c.sr, far_bound) ? c.node + 1 : n.link;
+                else phase = n.tag == TAG_END ? PH_SHADE : PH_SPECIAL;
             }
         } else {
             const int kind = n.tag & TAG_KIND_MASK;
             const bool trav = phase == PH_TRAV;
             const bool inner = trav && kind == TAG_INNER;
-            const bool inside = slab_hit(n, c.sr, (real)0.001, (real)c.closest);
+            const bool inside = slab_hit_any<real>(n, c.sr, far_bound);
             c.node = inner ? (inside ? c.node + 1 : n.link) : c.node;
             bool handled = inner;
             if ((FEAT & FEAT_BOX) && !MLRT_BOX_SPECIAL) {
                 const bool box = trav && kind == TAG_BOX;
                 if (box) {
                     double t; int aux = 0;
-                    if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+                    if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; far_bound = slab_far_bound(t); }
                     c.node += 1;
                 }
                 handled = handled || box;
