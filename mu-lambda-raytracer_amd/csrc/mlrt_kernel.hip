@@ -820,21 +820,24 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
     // (fast build: times the reciprocal - an f64 division is ~25 instructions, twice per sample)
     const double s = kFast ? ((double)i + u01d(b0)) * F.inv_wm1 : ((double)i + u01d(b0)) / ((double)P.width - 1.0);
     const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : ((double)j + u01d(b1)) / ((double)P.height - 1.0);
-    double rdx = 0.0, rdy = 0.0;
-    if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is
+    const P3 origin = ld3p(F.cam_origin);
+    const P3 through = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin;
+    if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is: nothing to add
         const double u1 = ((double)(b2 >> 8) + 1.0) * (1.0 / 16777216.0);
         const double turn = u01d(b3);
         double cs, sn;
         if (kFast) { cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
         else { const double phi = 2.0 * 3.14159265358979323846264338327950288 * turn; cs = cos(phi); sn = sin(phi); }
         const double r = sqrt(u1);
-        rdx = F.lens_radius * (r * cs);
-        rdy = F.lens_radius * (r * sn);
+        const double rdx = F.lens_radius * (r * cs);
+        const double rdy = F.lens_radius * (r * sn);
+        const P3 offset = ld3p(F.cam_u) * rdx + ld3p(F.cam_v) * rdy;
+        o = origin + offset;
+        d = through - offset;
+    } else {
+        o = origin;
+        d = through;
     }
-    const P3 offset = ld3p(F.cam_u) * rdx + ld3p(F.cam_v) * rdy;
-    const P3 origin = ld3p(F.cam_origin);
-    o = origin + offset;
-    d = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin - offset;
 }
 
 // 2^-32 fixed point; integer accumulation is order independent (within a tile in LDS, across tiles in HBM).  NaN/negative radiance cannot occur on this
