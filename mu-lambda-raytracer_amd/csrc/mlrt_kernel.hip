@@ -91,8 +91,9 @@ struct FrameParams {
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
     double lens_radius, inv_wm1, inv_hm1;
     MLRT_REAL bg_top[3], bg_bottom[3];
+    float through0[3], hor_f[3], ver_f[3], u_f[3], v_f[3];  // fast build: llc - origin, horizontal, vertical, u, v in f32
 };
-constexpr int kFrameParamBytes = 224;
+constexpr int kFrameParamBytes = 320;
 static_assert(sizeof(FrameParams) <= kFrameParamBytes, "FrameParams must fit its LDS slot");
 // the kernel copies cam_origin ... inv_hm1 as 21 consecutive doubles from the argument struct
 static_assert(offsetof(FrameParams, inv_hm1) - offsetof(FrameParams, cam_origin) == 20 * sizeof(double), "FrameParams: camera block layout");
@@ -817,6 +818,28 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
     uint32_t b0, b1, b2, b3;
     philox4x32_10(key.k0, key.k1, 0u, g.sample, g.pixel, 0u, b0, b1, b2, b3);
     g.draw = 4u;
+    if (kFast) {
+        // Fast build: the primary ray in f32 (the f64 sequence below is ~45 double-rate instructions per sample; sub-pixel
+        // position to 2^-13 pixel and direction to 1e-7 are far inside what a path tracer resolves, and inside the margins of
+        // the primary candidate lists); the origin stays exact.
+        const float sf = ((float)i + (float)(b0 >> 8) * (float)(1.0 / 16777216.0)) * (float)F.inv_wm1;
+        const float tf = ((float)j + (float)(b1 >> 8) * (float)(1.0 / 16777216.0)) * (float)F.inv_hm1;
+        float dx = F.through0[0] + sf * F.hor_f[0] + tf * F.ver_f[0];
+        float dy = F.through0[1] + sf * F.hor_f[1] + tf * F.ver_f[1];
+        float dz = F.through0[2] + sf * F.hor_f[2] + tf * F.ver_f[2];
+        o = ld3p(F.cam_origin);
+        if (P.has_lens) {
+            const float u1 = ((float)(b2 >> 8) + 1.0f) * (float)(1.0 / 16777216.0);
+            const float turn = (float)(b3 >> 8) * (float)(1.0 / 16777216.0);
+            const float r = (float)F.lens_radius * __builtin_amdgcn_sqrtf(u1);
+            const float rdx = r * __builtin_amdgcn_cosf(turn), rdy = r * __builtin_amdgcn_sinf(turn);
+            const float ox = F.u_f[0] * rdx + F.v_f[0] * rdy, oy = F.u_f[1] * rdx + F.v_f[1] * rdy, oz = F.u_f[2] * rdx + F.v_f[2] * rdy;
+            o = o + mkp((double)ox, (double)oy, (double)oz);
+            dx -= ox; dy -= oy; dz -= oz;
+        }
+        d = mkp((double)dx, (double)dy, (double)dz);
+        return;
+    }
     // (fast build: times the reciprocal - an f64 division is ~25 instructions, twice per sample)
     const double s = kFast ? ((double)i + u01d(b0)) * F.inv_wm1 : ((double)i + u01d(b0)) / ((double)P.width - 1.0);
     const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : ((double)j + u01d(b1)) / ((double)P.height - 1.0);
@@ -1024,7 +1047,12 @@ void mlrt_render_kernel(const KParams<real> P) {
     }
     FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytesPerWave);
     if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... inv_hm1 are contiguous in both structs
-    if (threadIdx.x < 3) { F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x]; }
+    if (threadIdx.x < 3) {
+        F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x];
+        F.through0[threadIdx.x] = (float)(P.cam_llc[threadIdx.x] - P.cam_origin[threadIdx.x]);
+        F.hor_f[threadIdx.x] = (float)P.cam_horizontal[threadIdx.x]; F.ver_f[threadIdx.x] = (float)P.cam_vertical[threadIdx.x];
+        F.u_f[threadIdx.x] = (float)P.cam_u[threadIdx.x]; F.v_f[threadIdx.x] = (float)P.cam_v[threadIdx.x];
+    }
     __syncthreads();
     Scene S;
     S.nodes = reinterpret_cast<const DNode<real>*>(base + P.off_nodes);
