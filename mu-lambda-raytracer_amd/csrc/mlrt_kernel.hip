@@ -319,9 +319,9 @@ DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
     if ((FEAT & FEAT_XFORM) && xf >= 0) to_object(S.nodes[xf], r.o, r.d);
     r.a = dfma(r.d.z, r.d.z, dfma(r.d.y, r.d.y, r.d.x * r.d.x));  // length_squared: x*x + y*y + z*z
     if (kFast) {
-        // 1/|d|^2 to f64 accuracy: f32 seed + 2 Newton steps (no f64 divide in the hot path)
+        // 1/|d|^2: f32 seed (1e-7) + ONE Newton step (1e-14: the roots carry that relative error, far below the f32 shading
+        // that consumes them; no f64 divide in the hot path)
         double x = (double)__builtin_amdgcn_rcpf((float)r.a);
-        x = x * dfma(-r.a, x, 2.0);
         x = x * dfma(-r.a, x, 2.0);
         r.inv_a = x;
     } else {
