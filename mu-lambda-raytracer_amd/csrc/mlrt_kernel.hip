@@ -398,15 +398,13 @@ DEV bool sphere_roots(const DNode<real>& n, const Ray& r, double& near_root, dou
     if (discriminant < 0.0) return false;
     double sqrtd;
     if (kFast) {
-        // sqrt to ~f64 accuracy: f32 rsqrt seed, one Newton step on y = 1/sqrt(x), then s = x*y corrected once
+        // sqrt to 1e-14: f32 rsqrt seed (1e-7), one Newton step on y = 1/sqrt(x), s = x*y (the same argument as for 1/|d|^2)
         if (discriminant == 0.0) {
             sqrtd = 0.0;
         } else {
             double y = (double)__builtin_amdgcn_rsqf((float)discriminant);
             y = y * dfma(-0.5 * discriminant, y * y, 1.5);
-            double s = discriminant * y;
-            s = dfma(0.5 * y, dfma(-s, s, discriminant), s);
-            sqrtd = s;
+            sqrtd = discriminant * y;
         }
         near_root = (-half_b - sqrtd) * r.inv_a;
         far_root = (-half_b + sqrtd) * r.inv_a;
