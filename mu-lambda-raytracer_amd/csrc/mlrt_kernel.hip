@@ -670,6 +670,11 @@ DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
     }
 }
 
+// Ray::at (vec.rs): origin + t * direction; one fma per component in the fast build
+DEV P3 ray_at(P3 o, P3 d, double t) {
+    if (kFast) return mkp(__builtin_fma(t, d.x, o.x), __builtin_fma(t, d.y, o.y), __builtin_fma(t, d.z, o.z));
+    return o + t * d;
+}
 // Shading in two halves.  hit_attributes: the closest hit the cursor found (point, normal, uv, material).  scatter: the
 // material response; returns true when the path continues with (o, d) replaced and `thr` multiplied by the attenuation,
 // false when it ends with radiance `emitted`.  Between the two the batch evaluates, for the whole wave at once, what a
@@ -692,14 +697,14 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
     const int mat_id = n.link;
     const V3 dw = to_v3(d);  // world direction in shading precision
     if ((FEAT & FEAT_MEDIUM) && kind == TAG_MEDIUM) {  // volumes.rs:55-63
-        p = o + c.closest * d;
+        p = ray_at(o, d, c.closest);
         normal = mk((real)1, (real)0, (real)0);
     } else {
         P3 oo = o, od = d;
         DNode<real> xf;
         xf.tag = 0;
         if ((FEAT & FEAT_XFORM) && c.hit_xf >= 0) { xf = S.nodes[c.hit_xf]; to_object(xf, oo, od); }
-        const P3 po = oo + c.closest * od;  // Ray::at
+        const P3 po = ray_at(oo, od, c.closest);
         const V3 odf = to_v3(od);
         V3 outward = mk(0, 0, 1);
         if (kind == TAG_SPHERE) {
