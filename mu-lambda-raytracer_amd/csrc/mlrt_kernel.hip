@@ -526,8 +526,7 @@ DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3
                 double ray_scale, inv_ray_scale = 0.0;
                 if (kFast) {
                     double y = (double)__builtin_amdgcn_rsqf((float)dd);
-                    y = y * dfma(-0.5 * dd, y * y, 1.5);
-                    y = y * dfma(-0.5 * dd, y * y, 1.5);
+                    y = y * dfma(-0.5 * dd, y * y, 1.5);  // 1e-14
                     inv_ray_scale = y;
                     ray_scale = dd * y;
                 } else {
@@ -535,7 +534,7 @@ DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3
                 }
                 const double distance_inside = (t2 - t1) * ray_scale;
                 const double xi = u01d(rng_next(g, key));
-                const double hit_distance = (double)n.v[0] * (kFast ? (double)logf((float)xi) : log(xi));
+                const double hit_distance = (double)n.v[0] * (kFast ? (double)(__builtin_amdgcn_logf((float)xi) * 0.693147180559945f) : log(xi));  // (v_log_f32 is log2; xi = 0 gives -inf: no hit, as with ln)
                 if (!(hit_distance > distance_inside)) {
                     c.closest = kFast ? dfma(hit_distance, inv_ray_scale, t1) : t1 + hit_distance / ray_scale;
                     c.hit_node = c.node; c.hit_aux = 0; c.hit_xf = c.xf;
