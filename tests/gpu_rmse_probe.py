@@ -8,3 +8,7 @@ for name, width, aspect, spp in (("random", 400, 1.5, 64), ("final_scene", 200, 
     rows = np.arange(0, mlrt.image_height(width, aspect), 3)
     got, ref, info = T.render_both(mlrt, oracle, name, width, aspect, spp, mlrt.PRECISION_FP32, rows=rows, earth=earth if name in ("earth", "final_scene") else None)
     print(name, "frac %.5f rmse %.2e maxdiff %d" % T.metrics(got, ref), flush=True)
+for name, width, aspect, spp in (("random_chk", 160, 1.5, 128), ("debug_perlin", 160, 1.0, 128), ("two_spheres", 160, 1.5, 128)):
+    rows = np.arange(0, mlrt.image_height(width, aspect), 3)
+    got, ref, info = T.render_both(mlrt, oracle, name, width, aspect, spp, mlrt.PRECISION_FP32, rows=rows, earth=None)
+    print(name, "frac %.5f rmse %.2e maxdiff %d" % T.metrics(got, ref), flush=True)
