@@ -173,6 +173,15 @@ def test_tile_geometry_does_not_change_the_image(mlrt, monkeypatch):
         images.append(r.render())
         r.close()
     monkeypatch.delenv("MLRT_TILE_SAMPLES")
+    # the tapering passes at the end of the queue and the number of sub-queues are tile geometry too
+    for tail, queues in (("", "1"), ("64", "8"), ("64,64,128", "2"), ("32,32,32,32,32,32,32,32", "64")):
+        monkeypatch.setenv("MLRT_TILE_TAIL", tail)
+        monkeypatch.setenv("MLRT_TILE_QUEUES", queues)
+        r = mlrt.Renderer(w, cam, params)
+        images.append(r.render())
+        r.close()
+    monkeypatch.delenv("MLRT_TILE_TAIL")
+    monkeypatch.delenv("MLRT_TILE_QUEUES")
     for img in images[1:]:
         assert np.array_equal(img, images[0])
     w.close()
