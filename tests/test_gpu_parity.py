@@ -100,6 +100,19 @@ def test_baseline_config2_rows_at_full_size(mlrt, oracle, precision_name):
 
 
 @pytest.mark.parametrize("precision_name", ["fp64", "fp32"])
+def test_baseline_config3_rows_at_full_size(mlrt, oracle, precision_name):
+    """BASELINE.json configs[2] (defocus blur: --aperture=0.1 --focus_dist=10.0) at its full size on a few rows: thin-lens
+    ray generation (f32 in the fast build) and the lens-widened primary candidate lists against the oracle."""
+    precision = mlrt.PRECISION_FP64 if precision_name == "fp64" else mlrt.PRECISION_FP32
+    got, ref, _ = render_both(mlrt, oracle, "random", 1200, 1.5, 500, precision, rows=[60, 400, 640], aperture=0.1, focus=10.0)
+    frac, rmse, maxdiff = metrics(got, ref)
+    if precision_name == "fp64":
+        assert frac <= 1e-4, (frac, rmse, maxdiff)
+    else:
+        assert rmse < 1e-3 and maxdiff <= 3, (frac, rmse, maxdiff)
+
+
+@pytest.mark.parametrize("precision_name", ["fp64", "fp32"])
 def test_baseline_config4_rows_at_full_size(mlrt, oracle, earthmap, precision_name):
     """BASELINE.json configs[3] geometry (final_scene 800x800: deep BVHs, emissive rect, media, image + noise textures)."""
     precision = mlrt.PRECISION_FP64 if precision_name == "fp64" else mlrt.PRECISION_FP32
