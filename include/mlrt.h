@@ -47,8 +47,12 @@ enum { MLRT_OBJ_PRIM = 0, MLRT_OBJ_BVH = 1, MLRT_OBJ_MEDIUM = 2 };
 /* src/raytrace.rs:8-48 */
 enum { MLRT_BG_BLACK = 0, MLRT_BG_GRADIENT = 1 };
 /* arithmetic of the device path */
-enum { MLRT_PRECISION_FP32 = 0, /* fast path: f32 rays/boxes, f64 island for the sphere quadratic */
-       MLRT_PRECISION_FP64 = 1  /* parity path: everything f64, reference operation order */ };
+enum { MLRT_PRECISION_FP32 = 0,       /* fast path: f32 boxes/rects/shading, f64 ray state and sphere quadratic */
+       MLRT_PRECISION_FP64 = 1,       /* reference precision (src/vec.rs:5-8): every operation that decides a sample's value is f64
+                                       * in the reference's operation order; the culling structure (SAH BVH, box wrappers,
+                                       * primary candidate lists) is the device's own and cannot change a closest hit */
+       MLRT_PRECISION_FP64_STRICT = 2 /* as FP64, plus the reference's BVH topology and AABB::hit arithmetic (bhv.rs:29-42,
+                                       * 122-165): exactly the tests the reference performs.  A test instrument (slow). */ };
 
 typedef struct mlrt_material {
     int32_t kind;     /* MLRT_MAT_* */
@@ -171,6 +175,28 @@ typedef struct mlrt_params {
  * logger, raytrace.rs:182; main.rs:157-173 only derives a throttled percentage from it). */
 typedef void (*mlrt_progress_fn)(int32_t rows_done, int32_t rows_total, void* user);
 
+/* Tuning and diagnostic switches of the device path.  None of them may change an image in the f64 modes (the
+ * culling structure and the tile geometry are result-neutral by construction; tests/test_gpu_properties.py checks
+ * each switch).  MLRT_PRECISION_FP64_STRICT ignores sah / leaf_wrap / primary_lists / lds_scene. */
+typedef struct mlrt_options {
+    int32_t sah;           /* 1: surface-area-heuristic device BVH; 0: the reference's topology (bhv.rs:122-145) */
+    int32_t leaf_wrap;     /* 1: bounding-box entries in front of sphere leaves and of top-level objects */
+    int32_t primary_lists; /* 1: per-pixel-group candidate lists for primary rays (sphere-only scenes) */
+    int32_t lds_scene;     /* 1: stage the packed scene in LDS when it fits */
+    int32_t force_full;    /* 1: always the FULL kernel variant */
+    int32_t tile_samples;  /* samples per big tile, >= 64 (default 512) */
+    int32_t tile_queues;   /* tile sub-queues, a power of two <= 64 (default 8) */
+    int32_t n_tail;        /* -1: adaptive tapering passes; else the number of entries of tail[] */
+    int32_t tail[8];       /* samples of the tapering passes, counted from the end of a pixel's sample range */
+    int32_t stats;         /* debug library only: in-kernel counters */
+    int32_t debug_pixel, debug_sample; /* debug library only: print the path of one (pixel, sample); -1 = off */
+} mlrt_options;
+void mlrt_options_default(mlrt_options* out);
+/* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,
+ * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL):
+ * the only place the library reads its environment. */
+void mlrt_options_from_env(mlrt_options* out);
+
 typedef struct mlrt_context mlrt_context;
 
 void mlrt_version(int32_t* major, int32_t* minor);
@@ -179,7 +205,8 @@ int32_t mlrt_device_count(void);
 
 /* Replaces Renderer::new_with_rng: validates the scene, packs it into the device layout (threaded BVH,
  * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*. */
-int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out);
+int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out); /* options from the environment */
+int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_t precision, const mlrt_options* options, mlrt_context** out);
 void mlrt_context_destroy(mlrt_context* ctx);
 
 /* Replaces Renderer::render.  Renders the rows listed in `rows` (row j = 0 is the BOTTOM row, quirk Q13;

@@ -17,7 +17,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "mlrt")
 EARTHMAP_PPM = os.path.join(os.path.dirname(_HERE), "assets", "earthmap.ppm")
 
 MLRT_OK, MLRT_ERR_INVALID, MLRT_ERR_NO_DEVICE, MLRT_ERR_HIP, MLRT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-PRECISION_FP32, PRECISION_FP64 = 0, 1
+PRECISION_FP32, PRECISION_FP64, PRECISION_FP64_STRICT = 0, 1, 2
 BG_BLACK, BG_GRADIENT = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 PRIM_SPHERE, PRIM_BOX, PRIM_RECT = 0, 1, 2
@@ -102,10 +102,18 @@ class Params(C.Structure):
                 ("background_bottom", C.c_double * 3)]
 
 
+class Options(C.Structure):
+    """mlrt_options (include/mlrt.h): tuning / diagnostic switches, none of which may change an f64 image."""
+    _fields_ = [("sah", C.c_int32), ("leaf_wrap", C.c_int32), ("primary_lists", C.c_int32), ("lds_scene", C.c_int32), ("force_full", C.c_int32),
+                ("tile_samples", C.c_int32), ("tile_queues", C.c_int32), ("n_tail", C.c_int32), ("tail", C.c_int32 * 8), ("stats", C.c_int32),
+                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32)]
+
+
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
 
 # every symbol declared in include/mlrt.h and include/mlrt_host.h
-EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_context_create", "mlrt_context_destroy", "mlrt_context_render",
+EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_options_default", "mlrt_options_from_env", "mlrt_context_create",
+                  "mlrt_context_create_opts", "mlrt_context_destroy", "mlrt_context_render",
                   "mlrt_context_render_device", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_render"]
 EXPORTS_MLRT_HOST_H = ["mlrt_world_count", "mlrt_world_name", "mlrt_world_build", "mlrt_world_free", "mlrt_world_scene", "mlrt_world_camera",
                        "mlrt_world_background", "mlrt_world_stream_probes", "mlrt_camera_new", "mlrt_image_height", "mlrt_write_p3",
@@ -139,6 +147,9 @@ def lib():
         L.mlrt_decode_jpeg_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mlrt_free.argtypes = [C.c_void_p]
         L.mlrt_context_create.argtypes = [C.POINTER(Scene), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.mlrt_context_create_opts.argtypes = [C.POINTER(Scene), C.c_int32, C.c_int32, C.POINTER(Options), C.POINTER(C.c_void_p)]
+        L.mlrt_options_default.argtypes = [C.POINTER(Options)]
+        L.mlrt_options_from_env.argtypes = [C.POINTER(Options)]
         L.mlrt_context_destroy.argtypes = [C.c_void_p]
         L.mlrt_context_render.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mlrt_context_render_device.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -181,6 +192,22 @@ def decode_jpeg(data):
     img = np.ctypeslib.as_array(out, shape=(h.value, w.value, 3)).copy()
     lib().mlrt_free(out)
     return img
+
+
+def options(**kw):
+    """mlrt_options_from_env() with fields overridden by keyword (tail=[...] sets n_tail too)."""
+    o = Options()
+    lib().mlrt_options_from_env(C.byref(o))
+    for k, v in kw.items():
+        if k == "tail":
+            o.n_tail = len(v)
+            for i, x in enumerate(v):
+                o.tail[i] = int(x)
+        else:
+            if not hasattr(o, k):
+                raise AttributeError("mlrt_options has no field %r" % k)
+            setattr(o, k, int(v))
+    return o
 
 
 def image_height(image_width, aspect_ratio):
@@ -258,10 +285,13 @@ def default_camera(world, aspect_ratio, aperture=0.0, focus_dist=None, vup=(0.0,
 class Renderer:
     """Renderer::new_with_rng(camera, world, background, params, RecursiveRayTracer{max_depth}, SeedableRngator(seed)) + render()."""
 
-    def __init__(self, world, camera, params, precision=PRECISION_FP32, device=0):
+    def __init__(self, world, camera, params, precision=PRECISION_FP32, device=0, opts=None):
         self.world, self.camera, self.params, self.precision, self.device = world, camera, params, precision, device
         ctx = C.c_void_p()
-        _check(lib().mlrt_context_create(world.scene, int(device), int(precision), C.byref(ctx)))
+        if opts is None:
+            _check(lib().mlrt_context_create(world.scene, int(device), int(precision), C.byref(ctx)))
+        else:
+            _check(lib().mlrt_context_create_opts(world.scene, int(device), int(precision), C.byref(opts), C.byref(ctx)))
         self.ctx = ctx
 
     def render(self, rows=None, progress=None):

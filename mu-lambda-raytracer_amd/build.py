@@ -28,6 +28,7 @@ if DEBUG:
     os.environ["MLRT_TAG"] = "_debug"
 TAG = os.environ.get("MLRT_TAG", "")
 EXTRA_KERNEL_FLAGS = os.environ.get("MLRT_KERNEL_FLAGS", "").split()
+EXTRA_KERNEL_FLAGS64 = os.environ.get("MLRT_KERNEL_FLAGS64", "").split()
 # the instrumented kernels need the registers the release kernels give up for occupancy: looser launch bounds
 DEBUG_FLAGS = ["-DMLRT_DEBUG_BUILD=1"] if DEBUG else []
 DEBUG_FLAGS_F32 = ["-DMLRT_LEAN_BLOCK=1024", "-DMLRT_LEAN_WAVES_PER_EU=4"] if DEBUG else []
@@ -46,8 +47,14 @@ UNITS = [
     # (the f64 geometry code fuses explicitly, see dfma), so the image does not depend on the compiler's inlining or on
     # which kernel variant runs.  Measured cost against -ffp-contract=fast: 1.5 % (C2) to 3.5 % (final_scene).
     ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
-    # parity build: no FMA contraction, so every rounding sits where the reference (and the oracle) has it
-    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256", "-DMLRT_LEAN_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
+    # reference-precision build (product mode): every rounding of a sample's arithmetic where the reference has it; big
+    # persistent workgroups, LDS-resident scene
+    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=" + os.environ.get("MLRT_BLOCK64", "512"),
+                              "-DMLRT_LEAN_BLOCK=" + os.environ.get("MLRT_LEAN_BLOCK64", "1024"), "-DMLRT_LEAN_WAVES_PER_EU=" + os.environ.get("MLRT_LEAN_WAVES64", "4"),
+                              "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES64", "2"), "-ffp-contract=off"] + EXTRA_KERNEL_FLAGS64 + DEBUG_FLAGS),
+    # strict build (test instrument): additionally the reference's BVH topology and slab arithmetic
+    ("kernel_f64s.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256",
+                               "-DMLRT_LEAN_WAVES_PER_EU=1", "-DMLRT_FULL_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),
     ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),
@@ -72,7 +79,7 @@ def _run(cmd):
 def build(force=False, verbose_resources=False):
     for d in (LIB_DIR, BIN_DIR, OBJ_DIR):
         os.makedirs(d, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for obj, src, extra in UNITS:
         out = os.path.join(OBJ_DIR, obj)
         objs.append(out)
@@ -80,7 +87,11 @@ def build(force=False, verbose_resources=False):
             cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", out]
             if verbose_resources and src == KERNEL:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-            _run(cmd)
+            cmds.append(cmd)
+    if cmds:  # the three kernel builds dominate: compile the stale units side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(cmds), int(os.environ.get("MLRT_BUILD_JOBS", "6")))) as pool:
+            list(pool.map(_run, cmds))
     if force or _stale(LIB, objs):
         _run([HIPCC, "-shared", "-fPIC", "-o", LIB] + objs)
     main_src = os.path.join(HERE, "host", "main.cpp")

@@ -15,22 +15,20 @@
 #include "../../include/mlrt.h"
 #include "mlrt_device.hpp"
 
-extern "C" {
+// One set of entry points per kernel build (mlrt_kernel.hip compiled with MLRT_SUFFIX = f32 | f64 | f64s).
 // variant: 0 = FULL (every feature), 1 = LEAN (see mlrt_kernel.hip)
-int mlrt_launch_f32(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
-int mlrt_launch_f64(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);
-int mlrt_instrumented_f32(void);
-int mlrt_instrumented_f64(void);
-uint32_t mlrt_variant_features_f32(int variant);
-uint32_t mlrt_variant_features_f64(int variant);
-int mlrt_block_threads_f32(int variant);
-int mlrt_block_threads_f64(int variant);
-int mlrt_acc_bytes_per_wave_f32(void);
-int mlrt_lds_frame_bytes_f32(void);
-int mlrt_lds_frame_bytes_f64(void);
-int mlrt_acc_bytes_per_wave_f64(void);
-int mlrt_occupancy_f32(int variant, int lds_scene, size_t dyn_lds);
-int mlrt_occupancy_f64(int variant, int lds_scene, size_t dyn_lds);
+#define MLRT_DECLARE_BUILD(sfx)                                                                                                    \
+    int mlrt_launch_##sfx(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);                \
+    int mlrt_instrumented_##sfx(void);                                                                                             \
+    uint32_t mlrt_variant_features_##sfx(int variant);                                                                             \
+    int mlrt_block_threads_##sfx(int variant);                                                                                     \
+    int mlrt_acc_bytes_per_wave_##sfx(void);                                                                                       \
+    int mlrt_lds_frame_bytes_##sfx(void);                                                                                          \
+    int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);
+extern "C" {
+MLRT_DECLARE_BUILD(f32)
+MLRT_DECLARE_BUILD(f64)
+MLRT_DECLARE_BUILD(f64s)
 }
 
 namespace mlrt {
@@ -38,6 +36,18 @@ void set_last_error(const std::string& msg);  // host/host_api.cpp (same library
 const char* last_error_cstr();
 
 namespace {
+
+struct KernelBuild {
+    int (*launch)(const void*, int, int, int, size_t, hipStream_t);
+    int (*instrumented)(void);
+    uint32_t (*variant_features)(int);
+    int (*block_threads)(int);
+    int (*acc_bytes_per_wave)(void);
+    int (*lds_frame_bytes)(void);
+    int (*occupancy)(int, int, size_t);
+};
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx}
+const KernelBuild kBuilds[3] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s)};  // indexed by MLRT_PRECISION_*
 
 struct Fail {
     int32_t code;
@@ -155,18 +165,23 @@ DNode<R> leaf_node(const mlrt_scene& s, const mlrt_prim_ref& p) {
     return n;
 }
 
-// Box bounds in the entry's precision, rounded OUTWARD so the f32 slab test stays conservative.
+// Box bounds in the entry's precision, moved OUTWARD so the culling test stays conservative: f32 entries by rounding
+// away from the box, f64 entries (where the conversion is exact) by 1e-12 relative - the product f64 build tests them by
+// reciprocal + fma, a few 1e-16 away from the division the primitive tests use.  `exact` (strict build): the reference's
+// own bounds, untouched.
 template <typename R>
-R round_down(double x) {
+R round_down(double x, bool exact = false) {
     R f = (R)x;
-    if (std::getenv("MLRT_NO_OUTWARD")) return f;
+    if (exact) return f;
+    if (sizeof(R) == 8) return (R)(x - 1e-12 * (1.0 + std::fabs(x)));
     if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<R>::infinity());
     return f;
 }
 template <typename R>
-R round_up(double x) {
+R round_up(double x, bool exact = false) {
     R f = (R)x;
-    if (std::getenv("MLRT_NO_OUTWARD")) return f;
+    if (exact) return f;
+    if (sizeof(R) == 8) return (R)(x + 1e-12 * (1.0 + std::fabs(x)));
     if ((double)f < x) f = std::nextafter(f, std::numeric_limits<R>::infinity());
     return f;
 }
@@ -196,7 +211,8 @@ void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out
     const mlrt_bvh_node& src = s.bvh_nodes[child];
     const size_t me = out.size();
     DNode<R> n{};
-    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(src.bounds_min[k]); n.v[3 + k] = round_up<R>(src.bounds_max[k]); }
+    // (wrap_leaves is off exactly in the strict build: the reference's bounds as they are)
+    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(src.bounds_min[k], !wrap_leaves); n.v[3 + k] = round_up<R>(src.bounds_max[k], !wrap_leaves); }
     n.tag = TAG_INNER;
     out.push_back(n);
     emit_subtree<R>(s, src.left, out, budget, wrap_leaves);
@@ -278,22 +294,12 @@ Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, 
     std::sort(items.begin() + begin, items.begin() + end, [best_axis](const SahItem& a, const SahItem& b) { return a.c[best_axis] < b.c[best_axis]; });
     const size_t me = out.size();
     out.push_back(DNode<R>{});
-    // Child order of the threaded walk.  Default: the child with the larger surface first (the likelier one to shrink
-    // the hit distance early).  MLRT_SAH_ORDER=none|eye are experiment hooks (eye: nearer to MLRT_EYE="x,y,z" first).
+    // Child order of the threaded walk: the child with the larger surface first (the likelier one to shrink the hit
+    // distance early; measured against input order, smaller-first and nearer-to-the-eye-first in round 1).
     Bounds lb = empty_bounds(), rb = empty_bounds();
     for (size_t i = begin; i < best_split; i++) lb.grow(items[i].b);
     for (size_t i = best_split; i < end; i++) rb.grow(items[i].b);
-    bool swap_children = rb.half_area() > lb.half_area();
-    if (const char* mode = std::getenv("MLRT_SAH_ORDER")) {
-        if (std::strcmp(mode, "none") == 0) swap_children = false;
-        if (std::strcmp(mode, "small") == 0) swap_children = !swap_children;
-        if (std::strcmp(mode, "eye") == 0) {
-            double e[3] = {0, 0, 0};
-            if (const char* eye = std::getenv("MLRT_EYE")) std::sscanf(eye, "%lf,%lf,%lf", &e[0], &e[1], &e[2]);
-            auto dist2 = [&](const Bounds& b) { double d = 0; for (int k = 0; k < 3; k++) { const double c = std::fmax(b.lo[k] - e[k], std::fmax(0.0, e[k] - b.hi[k])); d += c * c; } return d; };
-            swap_children = dist2(rb) < dist2(lb);
-        }
-    }
+    const bool swap_children = rb.half_area() > lb.half_area();
     if (swap_children) {
         std::rotate(items.begin() + begin, items.begin() + best_split, items.begin() + end);
         best_split = begin + (end - best_split);
@@ -464,6 +470,8 @@ using namespace mlrt;
 
 struct mlrt_context {
     int32_t device = 0, precision = MLRT_PRECISION_FP32;
+    mlrt_options opt{};  // read once at creation: nothing below looks at the environment
+    const KernelBuild* build = nullptr;
     int32_t n_cus = 0;
     unsigned char* d_blob = nullptr;
     int32_t blob_bytes = 0;
@@ -512,7 +520,7 @@ struct TilePlan {
     uint32_t n_groups_magic, tiles_per_row_magic;
     int32_t n_groups_shift, tiles_per_row_shift;
 };
-void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, TilePlan& T) {
+void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, const mlrt_options& opt, TilePlan& T) {
     // Tile geometry (see KParams).  Big chunks of ~MLRT_TILE_SAMPLES samples (default 512): enough to keep 64 lanes busy
     // through a tile's ramp-up, with per-tile work (queue atomics, the candidate record) small against it.  The last
     // samples of every pixel go out in tapering passes (sizes from the END of the sample range; MLRT_TILE_TAIL overrides):
@@ -521,23 +529,19 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, TilePla
     // for 1/1, 1/2, 1/4, 1/8 of C2's rows: no taper 47.6 25.0 14.1 8.6; "128" 48.4 24.7 13.1 7.8; "64,128" 49.5 25.2 13.1
     // 7.5; "64,64,128" 50.6 25.7 13.4 7.1) - and a small tile costs the FULL variant's expensive samples relatively less.
     // Low spp: several pixels per tile and a single pass.
-    int target = 512;
-    if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) target = std::max(64, std::atoi(ts));
+    const int target = std::max(64, opt.tile_samples);
     int pix = 1;
     T.n_big = 1; T.big = spp; T.n_tail = 0;
     for (int k = 0; k <= mlrt::kMaxTailPasses; k++) T.tail_s0[k] = spp;
     if (spp >= 128) {
         std::vector<int> tail;  // from the end
-        const char* spec = std::getenv("MLRT_TILE_TAIL");
-        if (!spec) {
+        if (opt.n_tail >= 0) {
+            for (int k = 0; k < opt.n_tail && k < mlrt::kMaxTailPasses; k++) if (opt.tail[k] > 0) tail.push_back(opt.tail[k]);
+        } else {
             const double big_tiles_per_wave = (double)width * n_rows * ((spp + target - 1) / target) / waves / (lean ? 1.0 : 2.0);
-            spec = big_tiles_per_wave >= 128 ? "" : big_tiles_per_wave >= 64 ? "128" : big_tiles_per_wave >= 32 ? "64,128" : big_tiles_per_wave >= 16 ? "64,64,128" : "64,64,64,64,128";
-        }
-        for (const char* q = spec; *q && (int)tail.size() < mlrt::kMaxTailPasses;) {
-            const int v = std::atoi(q);
-            if (v > 0) tail.push_back(v);
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
+            static const int kTaper[5] = {64, 64, 64, 64, 128};
+            const int depth = big_tiles_per_wave >= 128 ? 0 : big_tiles_per_wave >= 64 ? 1 : big_tiles_per_wave >= 32 ? 2 : big_tiles_per_wave >= 16 ? 3 : 5;
+            for (int k = 0; k < depth; k++) tail.push_back(kTaper[5 - depth + k]);  // "128" | "64,128" | "64,64,128" | "64,64,64,64,128"
         }
         int tail_total = 0, n_tail = 0;
         while (n_tail < (int)tail.size() && tail_total + tail[n_tail] <= spp - 64) tail_total += tail[n_tail++];  // the big passes keep >= 64 samples
@@ -572,8 +576,12 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, TilePla
     T.n_tiles = n_tiles64;
 }
 
-bool primary_lists_wanted(const mlrt_context* c, const mlrt_camera* cam, int image_height) {
-    return c->variant == 1 && c->n_nodes <= 4096 && image_height < 65536 && std::getenv("MLRT_NO_PRIMARY_LISTS") == nullptr;
+// Per-pixel-group primary candidate lists (mlrt_kernel.hip): the sphere-only variant, few enough entries that the pre-pass
+// stays small against the frame, and max_depth small enough for the list cursor the kernel keeps in the upper bits of a
+// lane's depth word (max_depth is any i32 in the reference: above 65535 the lanes simply walk the BVH).
+bool primary_lists_wanted(const mlrt_context* c, const mlrt_params* p) {
+    return c->variant == 1 && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && c->n_nodes <= 4096 && p->image_height < 65536 &&
+           p->max_depth <= 0xFFFF;
 }
 
 template <typename R>
@@ -598,7 +606,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
     TilePlan T;
-    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant == 1, T);
+    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant == 1, c->opt, T);
     MLRT_REQUIRE(T.n_tiles < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
     K.pix_per_tile = T.pix_per_tile; K.tiles_per_row = T.tiles_per_row; K.n_groups = T.n_groups; K.n_big = T.n_big; K.big = T.big; K.n_tail = T.n_tail;
     for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = T.tail_s0[k];
@@ -607,21 +615,17 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.tiles_per_row_magic = T.tiles_per_row_magic; K.tiles_per_row_shift = T.tiles_per_row_shift;
     const int pix = T.pix_per_tile;
     {   // cut the wave's accumulator area (mlrt_kernel.hip kAccBytesPerWave) into banks: sums + remaining/out/values + candidate list
-        const int area = c->precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64();
+        const int area = c->build->acc_bytes_per_wave();
         K.bank_values = 3 * pix;
         K.n_banks = std::max(1, std::min(16, (area - 16 * (12 + 32)) / (K.bank_values * 8)));  // kMaxBanks x (3 ints + candidate record)
     }
     K.acc_global = c->d_acc;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
-    K.n_queues = 8;
-    if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) { const int v = std::atoi(nq); if (v >= 1 && v <= mlrt::kMaxQueues && (v & (v - 1)) == 0) K.n_queues = v; }
+    K.n_queues = c->opt.tile_queues;
     K.stats = c->d_stats;
-    // per-pixel-group primary candidate lists (see mlrt_kernel.hip): the sphere-only variant, and few enough entries that
-    // the pre-pass's flat scan stays small against the frame
-    K.primary_lists = primary_lists_wanted(c, cam, p->image_height) ? c->d_cand : nullptr;
-    K.debug_pixel = -1; K.debug_sample = -1;
-    if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { K.debug_pixel = a; K.debug_sample = b; } }
+    K.primary_lists = primary_lists_wanted(c, p) ? c->d_cand : nullptr;
+    K.debug_pixel = c->opt.debug_pixel; K.debug_sample = c->opt.debug_sample;
 }
 
 void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) {
@@ -631,9 +635,14 @@ void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) 
     MLRT_REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     MLRT_REQUIRE((int64_t)p->image_width * p->image_height < (int64_t)1 << 31, "image too large for the 32-bit pixel counter of the Philox stream");
     MLRT_REQUIRE(n_rows >= 0 && n_rows <= p->image_height, "n_rows out of range");
+    MLRT_REQUIRE((int64_t)n_rows * p->image_width * 3 < (int64_t)1 << 31, "frame too large: n_rows * width * 3 must stay below 2^31 (32-bit indices of the accumulation buffer)");
     MLRT_REQUIRE(p->background_kind == MLRT_BG_BLACK || p->background_kind == MLRT_BG_GRADIENT, "unknown background kind");
 }
 
+// One frame: candidate pre-pass (sphere-only scenes), render kernel, resolve kernel - nothing else.  The accumulation
+// buffer and the tile counters are zero on entry: they are zeroed when allocated, and the resolve kernel leaves them
+// zeroed again after reading them (before: two hipMemsetAsync per frame, 23 MB for C2, which do not shrink with 1/N of
+// the rows per GPU).  A launch that fails leaves them undefined: the context must then be destroyed.
 void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb, double* d_accum,
             hipStream_t stream) {
     if (n_rows == 0) return;
@@ -645,9 +654,10 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
         if (c->d_acc) MLRT_HIP(hipFree(c->d_acc));
         c->d_acc = nullptr; c->acc_elems = 0;
         MLRT_HIP(hipMalloc(&c->d_acc, need * sizeof(unsigned long long)));
+        MLRT_HIP(hipMemset(c->d_acc, 0, need * sizeof(unsigned long long)));
         c->acc_elems = need;
     }
-    if (primary_lists_wanted(c, cam, p->image_height)) {  // one 32-byte record per pixel group; at most one group per pixel
+    if (primary_lists_wanted(c, p)) {  // one 32-byte record per pixel group; at most one group per pixel
         const size_t groups = (size_t)n_rows * (size_t)p->image_width;
         if (groups > c->cand_groups) {
             MLRT_HIP(hipStreamSynchronize(stream));
@@ -657,8 +667,6 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
             c->cand_groups = groups;
         }
     }
-    MLRT_HIP(hipMemsetAsync(c->d_acc, 0, need * sizeof(unsigned long long), stream));
-    MLRT_HIP(hipMemsetAsync(c->d_tile_counter, 0, mlrt::kMaxQueues * 64, stream));
     const int waves_per_block = c->block_threads / 64;
     int rc;
     int grid;
@@ -667,12 +675,12 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
         KParams<float> K{};
         fill_params<float>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
         grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
-        rc = mlrt_launch_f32(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+        rc = c->build->launch(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
     } else {
         KParams<double> K{};
         fill_params<double>(c, cam, p, d_rows, n_rows, d_rgb, d_accum, K);
         grid = std::max(1, std::min(c->n_cus * c->blocks_per_cu, (K.n_tiles + waves_per_block - 1) / waves_per_block));
-        rc = mlrt_launch_f64(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
+        rc = c->build->launch(&K, c->variant, c->lds_scene ? 1 : 0, grid, c->dyn_lds, stream);
     }
     if (rc != 0) throw Fail{MLRT_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)};
     MLRT_HIP(hipEventRecord(c->ev_stop, stream));
@@ -702,7 +710,9 @@ extern "C" {
 // tail_s0[0..8], n_tiles, n_groups_magic, n_groups_shift, tiles_per_row_magic, tiles_per_row_shift  (20 values)
 void mlrt_debug_tile_plan(int32_t width, int32_t n_rows, int32_t spp, int32_t waves, int32_t lean, int64_t* out) {
     TilePlan T;
-    plan_tiles(width, n_rows, spp, (double)waves, lean != 0, T);
+    mlrt_options o;
+    mlrt_options_from_env(&o);
+    plan_tiles(width, n_rows, spp, (double)waves, lean != 0, o, T);
     int k = 0;
     out[k++] = T.pix_per_tile; out[k++] = T.tiles_per_row; out[k++] = T.n_groups; out[k++] = T.n_big; out[k++] = T.big; out[k++] = T.n_tail;
     for (int i = 0; i <= mlrt::kMaxTailPasses; i++) out[k++] = T.tail_s0[i];
@@ -719,42 +729,85 @@ int32_t mlrt_device_count(void) {
     return n;
 }
 
+void mlrt_options_default(mlrt_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0;
+    o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
+    o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0;
+}
+// The MLRT_* environment variables (A/B scripts under tools/): read here and nowhere else, once per context.
+void mlrt_options_from_env(mlrt_options* o) {
+    if (!o) return;
+    mlrt_options_default(o);
+    if (std::getenv("MLRT_NO_SAH")) o->sah = 0;
+    if (std::getenv("MLRT_NO_LEAF_WRAP")) o->leaf_wrap = 0;
+    if (std::getenv("MLRT_NO_PRIMARY_LISTS")) o->primary_lists = 0;
+    if (std::getenv("MLRT_NO_LDS")) o->lds_scene = 0;
+    if (std::getenv("MLRT_FORCE_FULL")) o->force_full = 1;
+    if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) o->tile_samples = std::atoi(ts);
+    if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) o->tile_queues = std::atoi(nq);
+    if (const char* spec = std::getenv("MLRT_TILE_TAIL")) {
+        o->n_tail = 0;
+        for (const char* q = spec; *q && o->n_tail < 8;) {
+            const int v = std::atoi(q);
+            if (v > 0) o->tail[o->n_tail++] = v;
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
+    if (std::getenv("MLRT_STATS")) o->stats = 1;
+    if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { o->debug_pixel = a; o->debug_sample = b; } }
+}
+
 int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out) {
+    mlrt_options o;
+    mlrt_options_from_env(&o);
+    return mlrt_context_create_opts(scene, device, precision, &o, out);
+}
+
+int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_t precision, const mlrt_options* options, mlrt_context** out) {
     mlrt_context* c = nullptr;
     const int32_t rc = guarded([&] {
-        MLRT_REQUIRE(scene && out, "scene/out is NULL");
-        MLRT_REQUIRE(precision == MLRT_PRECISION_FP32 || precision == MLRT_PRECISION_FP64, "unknown precision");
+        MLRT_REQUIRE(scene && out && options, "scene/options/out is NULL");
+        MLRT_REQUIRE(precision == MLRT_PRECISION_FP32 || precision == MLRT_PRECISION_FP64 || precision == MLRT_PRECISION_FP64_STRICT, "unknown precision");
         *out = nullptr;
         validate(*scene);
+        MLRT_REQUIRE(options->tile_samples >= 64 && options->tile_samples <= (1 << 20), "options: tile_samples out of range");
+        MLRT_REQUIRE(options->tile_queues >= 1 && options->tile_queues <= mlrt::kMaxQueues && (options->tile_queues & (options->tile_queues - 1)) == 0,
+                     "options: tile_queues must be a power of two <= 64");
+        MLRT_REQUIRE(options->n_tail >= -1 && options->n_tail <= 8, "options: n_tail out of range");
         const int n_dev = mlrt_device_count();
         if (n_dev <= 0) throw Fail{MLRT_ERR_NO_DEVICE, "no HIP device is visible: libmlrt_hip has no CPU fallback"};
         MLRT_REQUIRE(device >= 0 && device < n_dev, "device ordinal out of range");
         c = new mlrt_context();
-        c->device = device; c->precision = precision;
+        c->device = device; c->precision = precision; c->opt = *options;
+        c->build = &kBuilds[precision];
+        const bool strict = precision == MLRT_PRECISION_FP64_STRICT;
         MLRT_HIP(hipSetDevice(device));
         hipDeviceProp_t prop;
         MLRT_HIP(hipGetDeviceProperties(&prop, device));
         c->n_cus = prop.multiProcessorCount;
-        // the leanest compiled kernel variant that covers the scene's features (MLRT_FORCE_FULL: experiment hook)
+        // the leanest compiled kernel variant that covers the scene's features
         c->features = scene_features(*scene);
-        const uint32_t lean = precision == MLRT_PRECISION_FP32 ? mlrt_variant_features_f32(1) : mlrt_variant_features_f64(1);
-        c->variant = ((c->features & ~lean) == 0 && std::getenv("MLRT_FORCE_FULL") == nullptr) ? 1 : 0;
+        const uint32_t lean = c->build->variant_features(1);
+        c->variant = ((c->features & ~lean) == 0 && !options->force_full) ? 1 : 0;
         std::vector<unsigned char> blob;
         const bool solid_only = c->variant == 1;  // the LEAN kernel variant reads no texture table (its scenes have SolidColor textures only)
+        c->block_threads = c->build->block_threads(c->variant);
         if (precision == MLRT_PRECISION_FP32) {
-            Packed<float> P = pack<float>(*scene, std::getenv("MLRT_NO_LEAF_WRAP") == nullptr, std::getenv("MLRT_NO_SAH") == nullptr, solid_only);
+            Packed<float> P = pack<float>(*scene, options->leaf_wrap != 0, options->sah != 0, solid_only);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
-            c->block_threads = mlrt_block_threads_f32(c->variant);
         } else {
-            Packed<double> P = pack<double>(*scene, false, false, solid_only);
+            // product f64: the same culling structure as the fast build over f64 entries; strict: the reference's structure verbatim
+            Packed<double> P = pack<double>(*scene, !strict && options->leaf_wrap != 0, !strict && options->sah != 0, solid_only);
             blob.swap(P.blob);
             const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
             std::memcpy(c->off, o, sizeof o);
             c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
-            c->block_threads = mlrt_block_threads_f64(c->variant);
         }
         c->blob_bytes = (int32_t)blob.size();
         MLRT_HIP(hipMalloc(&c->d_blob, blob.size()));
@@ -773,21 +826,27 @@ int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t pre
             MLRT_HIP(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DImage), hipMemcpyHostToDevice));
         }
         MLRT_HIP(hipMalloc(&c->d_tile_counter, mlrt::kMaxQueues * 64));
-        if (std::getenv("MLRT_STATS") || std::getenv("MLRT_DEBUG_PIXEL")) {
-            const bool instrumented = (precision == MLRT_PRECISION_FP64 ? mlrt_instrumented_f64() : mlrt_instrumented_f32()) != 0;
-            if (!instrumented) std::fprintf(stderr, "mlrt: MLRT_STATS / MLRT_DEBUG_PIXEL need the debug build of the library (python mu-lambda-raytracer_amd/build.py --debug; MLRT_LIB=.../libmlrt_hip_debug.so): ignored\n");
-            else if (std::getenv("MLRT_STATS")) { MLRT_HIP(hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long))); MLRT_HIP(hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long))); }
+        MLRT_HIP(hipMemset(c->d_tile_counter, 0, mlrt::kMaxQueues * 64));  // (every frame's resolve kernel leaves them zero again)
+        if (options->stats || options->debug_pixel >= 0) {
+            const bool instrumented = c->build->instrumented() != 0;
+            if (!instrumented) {
+                std::fprintf(stderr, "mlrt: stats / debug_pixel need the debug build of the library (python mu-lambda-raytracer_amd/build.py --debug; MLRT_LIB=.../libmlrt_hip_debug.so): ignored\n");
+                c->opt.stats = 0; c->opt.debug_pixel = -1;
+            } else if (options->stats) {
+                MLRT_HIP(hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)));
+                MLRT_HIP(hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long)));
+            }
         }
         MLRT_HIP(hipEventCreate(&c->ev_start));
         MLRT_HIP(hipEventCreate(&c->ev_stop));
-        // LDS plan: the f32 blob is staged in LDS when it fits next to the per-wave accumulators
+        // LDS plan: the blob is staged in LDS when it fits next to the per-wave accumulators and the frame parameters
+        // (the strict build is a test instrument: small workgroups reading the blob through L2)
         const int waves = c->block_threads / 64;
-        const size_t acc = (size_t)waves * (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_acc_bytes_per_wave_f32() : mlrt_acc_bytes_per_wave_f64())
-                           + (size_t)(precision == MLRT_PRECISION_FP32 ? mlrt_lds_frame_bytes_f32() : mlrt_lds_frame_bytes_f64());  // + the frame parameters
+        const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
         const size_t lds_limit = 160 * 1024;
-        c->lds_scene = precision == MLRT_PRECISION_FP32 && blob.size() + acc <= lds_limit && std::getenv("MLRT_NO_LDS") == nullptr;
+        c->lds_scene = !strict && blob.size() + acc <= lds_limit && options->lds_scene != 0;
         c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;
-        const int occ = precision == MLRT_PRECISION_FP32 ? mlrt_occupancy_f32(c->variant, c->lds_scene, c->dyn_lds) : mlrt_occupancy_f64(c->variant, c->lds_scene, c->dyn_lds);
+        const int occ = c->build->occupancy(c->variant, c->lds_scene, c->dyn_lds);
         c->blocks_per_cu = occ > 0 ? occ : 1;
         *out = c;
     });

@@ -1,9 +1,14 @@
 // csrc/mlrt_kernel.hip - the render megakernel for gfx950 (CDNA4, wave64).  Hand-written HIP; no MFMA (branchy
 // intersection arithmetic, not a contraction), no CUDA shims, no second back end.
 //
-// Compiled twice (see mu-lambda-raytracer_amd/build.py), both with -ffp-contract=off:
-//   -DMLRT_REAL=float                        -> fast path:   f64 ray state + sphere quadratic, f32 boxes/rects/shading
-//   -DMLRT_REAL=double -ffp-contract=off     -> parity path: f64 throughout, the reference's operation order
+// Compiled three times (see mu-lambda-raytracer_amd/build.py), all with -ffp-contract=off:
+//   -DMLRT_REAL=float                  -> fast path (f32):    f64 ray state + sphere quadratic, f32 boxes/rects/shading
+//   -DMLRT_REAL=double                 -> product path (f64): every operation that decides a sample's value is f64 in the
+//                                         reference's operation order; only the CULLING tests differ from the reference
+//                                         (SAH topology, box wrappers, slab test by reciprocal + fma with an outward slack,
+//                                         primary candidate lists): none of them can change a closest hit
+//   -DMLRT_REAL=double -DMLRT_STRICT=1 -> strict path (f64):  additionally the reference's BVH topology and its slab test
+//                                         with divisions (bhv.rs:29-42), i.e. exactly the tests the reference performs
 //
 // What it replaces (reference file:line):
 //   Renderer::render / render_line / render_pixel   raytrace.rs:162-198   -> tile queue + per-lane path regeneration
@@ -61,7 +66,7 @@
 #define MLRT_CAT_(a, b) a##b
 #define MLRT_CAT(a, b) MLRT_CAT_(a, b)
 #ifndef MLRT_SUFFIX
-#error "compile with -DMLRT_SUFFIX=f32 or f64"
+#error "compile with -DMLRT_SUFFIX=f32, f64 or f64s"
 #endif
 #define MLRT_NS MLRT_CAT(mlrt_, MLRT_SUFFIX)
 
@@ -71,6 +76,16 @@ using namespace mlrt;
 
 typedef MLRT_REAL real;
 constexpr bool kFast = sizeof(real) == 4;
+#ifdef MLRT_STRICT
+constexpr bool kStrict = true;   // reference slab arithmetic (the packer also keeps the reference topology)
+#else
+constexpr bool kStrict = false;
+#endif
+static_assert(!(kFast && kStrict), "the strict build is an f64 build");
+constexpr bool kProduct64 = !kFast && !kStrict;
+// Outward slack of the product f64 build's culling tests: reciprocal + fma instead of the reference's division moves a
+// slab distance by a few 1e-16 relative; 1e-12 is far outside that and far inside anything a box can wrongly admit.
+constexpr double kCullSlack64 = 1.0 + 1e-12;
 // Per wave: kAccBytesPerWave bytes of LDS holding the accumulator banks, one per tile in flight (the one being handed out
 // and older ones whose last paths are still running): [remaining | out | values][kMaxBanks] ints, the
 // candidate records, then the sums - n_banks x bank_values of them, cut at run time (KParams): one-pixel tiles get all 16
@@ -275,7 +290,15 @@ struct SlabRay {
 // subtraction and division (bhv.rs:33-35).
 DEV real slab_t(real k, real of, real invd) {
     if (kFast) return (real)__builtin_fmaf((float)k, (float)invd, (float)of);
+    if (kProduct64) return (real)__builtin_fma((double)k, (double)invd, (double)of);  // culling only (see kCullSlack64)
     return (k - of) / invd;
+}
+// The reference's own t = (k - origin) / direction in every build whose `real` is f64: the distance of an ACCEPTED face hit
+// (Block = six AARects, aarects.rs:46) must not carry the culling form's rounding.
+template <bool EXACT>
+DEV real face_t(real k, real of, real invd) {
+    if (EXACT) return (k - of) / invd;
+    return slab_t(k, of, invd);
 }
 // The f64 ray for the primitive tests.
 struct Ray {
@@ -340,9 +363,25 @@ DEV SlabRay slab_ray(const Ray& r) {
         q.invd = mk(fast_rcp((real)(fabsf(dx) < tiny ? copysignf(tiny, dx) : dx)), fast_rcp((real)(fabsf(dy) < tiny ? copysignf(tiny, dy) : dy)),
                     fast_rcp((real)(fabsf(dz) < tiny ? copysignf(tiny, dz) : dz)));
         q.of = mk(-(q.of.x * q.invd.x), -(q.of.y * q.invd.y), -(q.of.z * q.invd.z));
+    } else if (kProduct64) {
+        // the same form in f64: 1/d by v_rcp_f64 + one Newton step (~1e-16; the slack is 1e-12), |d| floored at 1e-300
+        const double tiny = 1e-300;
+        const double dx = fabs(r.d.x) < tiny ? copysign(tiny, r.d.x) : r.d.x, dy = fabs(r.d.y) < tiny ? copysign(tiny, r.d.y) : r.d.y,
+                     dz = fabs(r.d.z) < tiny ? copysign(tiny, r.d.z) : r.d.z;
+        double ix = __builtin_amdgcn_rcp(dx), iy = __builtin_amdgcn_rcp(dy), iz = __builtin_amdgcn_rcp(dz);
+        ix = ix * __builtin_fma(-dx, ix, 2.0); iy = iy * __builtin_fma(-dy, iy, 2.0); iz = iz * __builtin_fma(-dz, iz, 2.0);
+        q.invd = mk((real)ix, (real)iy, (real)iz);
+        q.of = mk((real)-(r.o.x * ix), (real)-(r.o.y * iy), (real)-(r.o.z * iz));
     } else {
         q.invd = to_v3(r.d);
     }
+    return q;
+}
+// The ray as the reference's own (k - o) / d wants it (face_t<true>).
+DEV SlabRay exact_slab_ray(const Ray& r) {
+    SlabRay q;
+    q.of = to_v3(r.o);
+    q.invd = to_v3(r.d);
     return q;
 }
 
@@ -359,6 +398,7 @@ DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) 
 #ifndef MLRT_NO_ROBUST
     if (kFast) return !(tmax * (real)1.0000003 <= tmin);
 #endif
+    if (kProduct64) return !(tmax * (real)kCullSlack64 <= tmin);
     return !(tmax <= tmin);
 }
 // The same decision for the fast build with two instructions less per step: the far bound min(far, closest) * slack is
@@ -376,7 +416,7 @@ DEV bool slab_hit_fast(const DNode<float>& n, const SlabRay& r, float closest_sl
     return !(tfar * 1.0000003f <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
 }
 // closest-so-far as the slab tests of the current build want it
-DEV real slab_far_bound(double closest) { return kFast ? (real)((float)closest * 1.0000003f) : (real)closest; }
+DEV real slab_far_bound(double closest) { return kFast ? (real)((float)closest * 1.0000003f) : (real)closest; }  // (f64 product: slab_hit applies the slack)
 template <typename R>
 DEV bool slab_hit_any(const DNode<R>& n, const SlabRay& r, R far_bound) {
     if constexpr (sizeof(R) == 4) return slab_hit_fast(n, r, far_bound);
@@ -429,12 +469,13 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
 // Block::hit = HittableList of six AARects (shapes.rs:172-192, hittable.rs:53-69): the nearest face hit inside
 // [tmin, tmax].  The faces a line can hit inside their rectangles are the slab entry and exit faces, so the six
 // rect tests collapse into one slab evaluation with the same t = (k - o)/d per face.
+template <bool EXACT>
 DEV bool box_hit(const DNode<real>& n, const SlabRay& r, double tmin, double tmax, double& t_out, int& axis_out) {
     real lo[3], hi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const real oa = comp(r.of, a), ia = comp(r.invd, a);
-        const real t0 = slab_t(n.v[a], oa, ia), t1 = slab_t(n.v[3 + a], oa, ia);
+        const real t0 = face_t<EXACT>(n.v[a], oa, ia), t1 = face_t<EXACT>(n.v[3 + a], oa, ia);
         lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
     }
     real te = lo[0]; int ae = 0;
@@ -474,7 +515,11 @@ template <uint32_t FEAT>
 DEV bool prim_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
     const int kind = n.tag & TAG_KIND_MASK;
     if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
-    if ((FEAT & FEAT_BOX) && kind == TAG_BOX) return box_hit(n, slab_ray(r), tmin, tmax, t_out, aux);
+    if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
+        // fast build: the culling form's t (one fma per face); f64 builds: the reference's division
+        if (kFast) return box_hit<false>(n, slab_ray(r), tmin, tmax, t_out, aux);
+        return box_hit<true>(n, exact_slab_ray(r), tmin, tmax, t_out, aux);
+    }
     if ((FEAT & FEAT_RECT) && kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
     return false;  // TAG_EMPTY: shapes.rs:8-23
 }
@@ -1166,14 +1211,22 @@ void mlrt_render_kernel(const KParams<real> P) {
             const bool inside = slab_hit_any<real>(n, c.sr, far_bound);
             c.node = inner ? (inside ? c.node + 1 : n.link) : c.node;
             bool handled = inner;
-            if ((FEAT & FEAT_BOX) && !MLRT_BOX_SPECIAL) {
+            if ((FEAT & FEAT_BOX) && !MLRT_BOX_SPECIAL && !kProduct64) {
+                // (c.sr is the culling form of the ray in the fast build and the reference's own (o, d) in the strict build)
                 const bool box = trav && kind == TAG_BOX;
                 if (box) {
                     double t; int aux = 0;
-                    if (box_hit(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; far_bound = slab_far_bound(t); }
+                    if (box_hit<kStrict>(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; far_bound = slab_far_bound(t); }
                     c.node += 1;
                 }
                 handled = handled || box;
+            }
+            if ((FEAT & FEAT_BOX) && kProduct64) {
+                // product f64 build: a Block the ray's culling test misses is passed in the step; one it may hit parks the lane
+                // for the special batch, where the face distances are the reference's divisions (box_hit<true>)
+                const bool box_missed = trav && kind == TAG_BOX && !inside;
+                c.node = box_missed ? c.node + 1 : c.node;
+                handled = handled || box_missed;
             }
             phase = (trav && !handled) ? (kind == TAG_END ? PH_SHADE : PH_SPECIAL) : phase;
         }
@@ -1369,10 +1422,14 @@ void mlrt_render_kernel(const KParams<real> P) {
     }
 }
 
-// to_rgb (raytrace.rs:59-68) in f64 over the finished accumulation buffer.
-__global__ void mlrt_resolve_kernel(const unsigned long long* acc, int n, int spp, int32_t* rgb_out, double* accum_out) {
+// to_rgb (raytrace.rs:59-68) in f64 over the finished accumulation buffer.  The kernel also leaves the frame's scratch the
+// way the next frame wants to find it - the sums it has read and the tile counters zero - so a frame is three launches
+// and no memset (a 23 MB hipMemsetAsync per C2 frame does not shrink when a GPU renders 1/8 of the rows).
+__global__ void mlrt_resolve_kernel(unsigned long long* acc, int n, int spp, int32_t* rgb_out, double* accum_out, unsigned int* tile_counter) {
+    if (blockIdx.x == 0 && threadIdx.x < kMaxQueues) tile_counter[threadIdx.x * 16] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double sum = (double)acc[i] * (1.0 / 4294967296.0);
+        acc[i] = 0ull;
         if (accum_out) accum_out[i] = sum;
         const double scale = 1.0 / (double)spp;
         double cc = sqrt(sum * scale);
@@ -1426,7 +1483,7 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
     {
         const int n = P.n_rows * P.width * 3;
         const int rgrid = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
-        hipLaunchKernelGGL(MLRT_NS::mlrt_resolve_kernel, dim3((unsigned)rgrid), dim3(256), 0, stream, P.acc_global, n, P.spp, P.rgb_out, P.accum_out);
+        hipLaunchKernelGGL(MLRT_NS::mlrt_resolve_kernel, dim3((unsigned)rgrid), dim3(256), 0, stream, P.acc_global, n, P.spp, P.rgb_out, P.accum_out, P.tile_counter);
     }
     return (int)hipGetLastError();
 }
