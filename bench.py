@@ -1,15 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py - BASELINE.json's metric on BASELINE.json's config:
-Msamples/s (pixels*spp) for --world=random --seed=42 1200x800 spp=500 (configs[1], the book-1 cover scene).
+"""bench.py - BASELINE.json's metric on BASELINE.json's configs, at the reference's precision.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4|c5] [--precision fp64|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one full render of the image through the C ABI (mlrt_context_render_device) with the scene already
-resident in HBM.  With N > 1 the image's rows are dealt to the ranks round-robin (strong scaling: the image is
-fixed), each rank renders its rows on its own GPU and ONE RCCL gather (torch.distributed, backend nccl) collects the
-8-bit-valued rows on rank 0 inside the timed region (mu-lambda-raytracer_amd/rowtile.py).  PyTorch is plumbing only:
-device buffers, streams, the process group.
+Headline (`value`, `dtype: "f64"`): Msamples/s of the f64 product mode (MLRT_PRECISION_FP64: every operation that decides
+a sample's value in f64 in the reference's operation order, /root/reference/src/vec.rs:5-8) on configs[1] =
+--world=random --seed=42 1200x800 spp 500.  The mixed-precision fast build (f32 boxes / shading, f64 ray state and
+sphere quadratic) is reported next to it as the `fast` sub-record with its measured RMSE against the f64 image of the
+same run - it is a mode of the product, not the number the reference is compared with.
+
+A "step" is one full render of the image through the C ABI (mlrt_context_render_device) with the scene already resident
+in HBM.  With N > 1 the image's rows are dealt to the ranks round-robin (strong scaling: the image is fixed), each rank
+renders its rows on its own GPU and ONE RCCL gather (torch.distributed, backend nccl) collects the 8-bit-valued rows on
+rank 0 inside the timed region (mu-lambda-raytracer_amd/rowtile.py).  PyTorch is plumbing only: device buffers,
+streams, the process group.
+
+`roofline`: the render kernel is bound by vector-instruction issue, not by HBM (the scene is LDS resident; physical HBM
+traffic is ~0.1 % of peak): `bound: "valu"`, achieved = wave-level VALU instructions per second = the kernel's
+SQ_INSTS_VALU per launch (rocprofv3 PMC, committed under profiles/, named in `roofline.profile`) / the kernel time
+measured live with HIP events; peak = 1 wave-instruction per 2 cycles per SIMD-32 x 1024 SIMDs x 2.4 GHz
+(MI355X_MICROARCH.md).  Lane utilisation and the LDS bank-conflict share ride along.  SURVEY 8(d)'s algorithmic-bytes
+figure is kept as `reference_work_equivalent` (what the REFERENCE's traversal would read for the same samples, counts
+from this run's cpu_baseline): it is not a utilisation and can exceed HBM peak.
 """
 import argparse
 import importlib
@@ -22,47 +35,109 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WORKLOAD = {"world": "random", "seed": 42, "aspect_ratio": "3:2", "image_width": 1200, "image_height": 800, "samples_per_pixel": 500, "max_depth": 50}
-# Algorithmic bytes per sample for this workload (DESIGN.md "Roofline"): counts measured by the instrumented oracle on
-# the reference BVH topology (tests/test_oracle_golden_images.py keeps them in range), device fp32 record sizes:
-# 85.4 box tests x 32 B + 10.8 sphere tests x 20 B + 2.56 rays x 16 B material + 12 B/pixel output / spp.
-ALGO_BYTES_PER_SAMPLE = 85.4 * 32 + 10.8 * 20 + 2.56 * 16 + 12.0 / 500
+CONFIGS = {
+    # BASELINE.json configs[1..4]
+    "c2": {"world": "random", "seed": 42, "aspect": 1.5, "aspect_ratio": "3:2", "image_width": 1200, "samples_per_pixel": 500, "max_depth": 50,
+           "aperture": 0.0, "focus_dist": None, "baseline": "configs[1]", "metric": "Msamples/sec (pixels*spp) --world=random 1200x800 spp=500"},
+    "c3": {"world": "random", "seed": 42, "aspect": 1.5, "aspect_ratio": "3:2", "image_width": 1200, "samples_per_pixel": 500, "max_depth": 50,
+           "aperture": 0.1, "focus_dist": 10.0, "baseline": "configs[2]", "metric": "Msamples/sec (pixels*spp) --world=random --aperture=0.1 --focus_dist=10.0 1200x800 spp=500"},
+    "c4": {"world": "final_scene", "seed": 42, "aspect": 1.0, "aspect_ratio": "1:1", "image_width": 800, "samples_per_pixel": 1000, "max_depth": 50,
+           "aperture": 0.0, "focus_dist": None, "baseline": "configs[3]", "metric": "Msamples/sec (pixels*spp) --world=final_scene 800x800 spp=1000"},
+    "c5": {"world": "final_scene", "seed": 42, "aspect": 1.0, "aspect_ratio": "1:1", "image_width": 800, "samples_per_pixel": 10000, "max_depth": 50,
+           "aperture": 0.0, "focus_dist": None, "baseline": "configs[4]", "metric": "Msamples/sec (pixels*spp) --world=final_scene 800x800 spp=10000 row-tiled"},
+}
+SIMDS, CLOCK_GHZ = 1024, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, max clock 2400 MHz
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Device fp32 record sizes of SURVEY 8(d)'s algorithmic-bytes figure
+REF_BYTES = {"aabb_tests": 32.0, "sphere_tests": 20.0, "rect_tests": 24.0, "scatters": 16.0, "noise_evals": 1008.0, "texel_fetches": 3.0}
+# rough CPU cost of the oracle per sample per thread, to size the bounded CPU sample
+CPU_US_PER_SAMPLE = {"random": 3.5, "final_scene": 6.1}
 
 
-def cpu_baseline(pkg, cam19, seconds_budget=20.0):
+def cpu_baseline(cfg, cam19, height, seconds_budget=15.0):
     """The oracle (kind "port": a C++ restatement - the Rust reference cannot be built here) with the reference's own
-    per-row PCG64 streams on a bounded sample of the same workload: evenly spaced rows, all host cores."""
+    per-row PCG64 streams on a bounded sample of the same workload: evenly spaced rows, all host cores; at the spp of the
+    config when a row fits the budget, else at reduced spp (samples are independent: cost is linear in spp)."""
     import numpy as np
     import oracle_binding
     oracle = oracle_binding.Oracle()
-    ow = oracle.world(WORKLOAD["world"], WORKLOAD["seed"])
+    earth = None
+    if cfg["world"] in ("earth", "final_scene"):
+        pkg = importlib.import_module("mu-lambda-raytracer_amd")
+        earth = pkg.load_earthmap()
+    ow = oracle.world(cfg["world"], cfg["seed"], earth)
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
     threads = max(1, min(threads, 32))
-    w, h, spp = WORKLOAD["image_width"], WORKLOAD["image_height"], WORKLOAD["samples_per_pixel"]
-    rows = np.unique(np.linspace(0, h - 1, min(h, 6 * threads)).astype(np.int32))  # 0.6 Msamples per row: ~13 s on 32 threads
-    _, _, stats, secs = ow.render(cam19, w, h, spp, seed=WORKLOAD["seed"], rng_mode=oracle_binding.RNG_PCG_ROW, rows=rows, threads=threads)
+    w, spp = cfg["image_width"], cfg["samples_per_pixel"]
+    us = CPU_US_PER_SAMPLE.get(cfg["world"], 5.0)
+    sample_budget = seconds_budget * threads / (us * 1e-6)
+    spp_cpu = spp
+    while w * spp_cpu * threads > sample_budget and spp_cpu > 50:  # at least one row per thread
+        spp_cpu //= 2
+    n_rows = int(max(threads, min(height, sample_budget / (w * spp_cpu))))
+    n_rows = max(threads, (n_rows // threads) * threads)
+    rows = np.unique(np.linspace(0, height - 1, min(height, n_rows)).astype(np.int32))
+    _, _, stats, secs = ow.render(cam19, w, height, spp_cpu, seed=cfg["seed"], rng_mode=oracle_binding.RNG_PCG_ROW, rows=rows, threads=threads)
     ow.close()
-    samples = len(rows) * w * spp
+    samples = len(rows) * w * spp_cpu
     return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "%d evenly spaced rows of the %dx%d spp=%d image (%.1f Msamples, %.1f s), PCG64 row streams, f64 C++ restatement of the Rust reference"
-                      % (len(rows), w, h, spp, samples / 1e6, secs),
+            "sample": "%d evenly spaced rows of the %dx%d image at spp %d%s (%.1f Msamples, %.1f s), PCG64 row streams, f64 C++ restatement of the Rust reference"
+                      % (len(rows), w, height, spp_cpu, "" if spp_cpu == spp else " (config: %d; cost is linear in spp)" % spp, samples / 1e6, secs),
             "stats_per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"}}
+
+
+def load_profile(config, dtype):
+    """The committed PMC summary for this (config, dtype): profiles/r02_pmc_<config>_<dtype>.json (tools/gpu_pmc.sh)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s_%s.json" % (config, dtype))
+    if not os.path.exists(path):
+        return None, None
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
+    prof, prof_path = load_profile(config, dtype)
+    out = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64 VALU instructions)", "frac": None, "traffic": None,
+           "profile": prof_path, "kernel_ms": kernel_ms,
+           "peak_note": "1 wave-instruction / 2 cycles / SIMD-32 x %d SIMDs x %.1f GHz; f64 and transcendental instructions occupy the pipe 2-8x longer "
+                        "(tools/microbench/valu_issue.hip), so 1.0 is not reachable by this instruction mix" % (SIMDS, CLOCK_GHZ)}
+    if prof:
+        per_sample = prof["valu_insts_per_sample"]
+        achieved = per_sample * my_samples / (kernel_ms * 1e-3) / 1e9
+        out.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_insts_per_sample": per_sample,
+                    "lane_utilisation": prof.get("lane_utilisation"), "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
+                    "profile_frac_at_capture": prof.get("valu_issue_frac"), "traffic": prof.get("hbm_bytes_per_launch")})
+        if prof.get("hbm_bytes_per_launch"):
+            out["hbm_physical_GBps"] = prof["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            out["hbm_physical_frac"] = out["hbm_physical_GBps"] / HBM_PEAK_GBS
+    if cpu_stats:
+        b = sum(REF_BYTES[k] * cpu_stats.get(k, 0.0) for k in REF_BYTES) + 12.0 / spp
+        out["reference_work_equivalent"] = {
+            "bytes_per_sample": b, "GBps": b * my_samples / (kernel_ms * 1e-3) / 1e9,
+            "note": "SURVEY 8(d): bytes the REFERENCE traversal (its BVH topology, counts from this run's cpu_baseline.stats_per_sample) would read "
+                    "for the same samples in the device's fp32 record sizes; not a utilisation of anything - the device BVH is SAH-built and LDS resident"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"], help="the headline mode (default: the reference's precision)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the fast (f32) sub-record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (rows gathered through host memory) only to rehearse N>1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import numpy as np
     import torch
@@ -92,82 +167,104 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    W, H, spp = WORKLOAD["image_width"], WORKLOAD["image_height"], WORKLOAD["samples_per_pixel"]
-    world = pkg.World(WORKLOAD["world"], WORKLOAD["seed"])
-    cam = pkg.default_camera(world, 1.5)
-    params = pkg.make_params(world, W, H, spp, WORKLOAD["max_depth"])
-    precision = pkg.PRECISION_FP32 if args.precision == "fp32" else pkg.PRECISION_FP64
-    renderer = pkg.Renderer(world, cam, params, precision=precision, device=device_index)
-
+    W, spp = cfg["image_width"], cfg["samples_per_pixel"]
+    H = pkg.image_height(W, cfg["aspect"])
+    world = pkg.World(cfg["world"], cfg["seed"])
+    cam = pkg.default_camera(world, cfg["aspect"], cfg["aperture"], cfg["focus_dist"])
+    params = pkg.make_params(world, W, H, spp, cfg["max_depth"])
     my_rows = rowtile.rows_for_rank(H, rank, world_size)
     d_rows = torch.tensor(my_rows, dtype=torch.int32, device=dev)
-    d_rgb = torch.zeros((len(my_rows), W, 3), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
     gather_device = torch.device("cpu") if (args.backend == "gloo" and world_size > 1) else dev  # gloo: rehearsal only
     gatherer = rowtile.RowGatherer(H, W, rank, world_size, gather_device)
-    frame = {}
-
-    def step():
-        renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
-        # the one collective of the path: finished rows to rank 0 over xGMI (a plain scatter into the frame at N = 1)
-        frame["image"] = gatherer.gather(d_rgb if gather_device == dev else d_rgb.cpu())
 
     def barrier():
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms = []
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # dominant kernel: the library's own HIP events around the last launch on the launch stream
-    kernel_ms = renderer.last_kernel_ms()
-    step_ms_events = [a.elapsed_time(b) for a, b in ev]
+    def measure(precision, steps, warmup):
+        """W untimed + K timed steps of one precision mode; returns (seconds [max over ranks], per-step HIP-event ms, last kernel ms, info, frame)."""
+        renderer = pkg.Renderer(world, cam, params, precision=precision, device=device_index)
+        d_rgb = torch.zeros((len(my_rows), W, 3), dtype=torch.int32, device=dev)
+        frame = {}
+
+        def step():
+            renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
+            # the one collective of the path: finished rows to rank 0 over xGMI (a plain scatter into the frame at N = 1)
+            frame["image"] = gatherer.gather(d_rgb if gather_device == dev else d_rgb.cpu())
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        # HIP events on the launch stream around every launch (candidate pre-pass + render kernel + resolve kernel), before the gather
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+        def timed_step(k):
+            ev[k][0].record(stream)
+            renderer.render_device(d_rows.data_ptr(), len(my_rows), d_rgb.data_ptr(), None, stream.cuda_stream)
+            ev[k][1].record(stream)
+            frame["image"] = gatherer.gather(d_rgb if gather_device == dev else d_rgb.cpu())
+
+        t0 = time.perf_counter()
+        for k in range(steps):
+            timed_step(k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world_size > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        step_ms = [a.elapsed_time(b) for a, b in ev]
+        kernel_ms = float(sum(step_ms) / len(step_ms))  # average launch duration over the timed region
+        info = renderer.info()
+        image = None if frame["image"] is None else frame["image"].clone()
+        renderer.close()
+        return elapsed, step_ms, kernel_ms, info, image
+
+    head_prec = pkg.PRECISION_FP64 if args.precision == "fp64" else pkg.PRECISION_FP32
+    head_dtype = "f64" if args.precision == "fp64" else "f32"
+    elapsed, step_ms, kernel_ms, info, image = measure(head_prec, args.steps, args.warmup)
+    fast = None
+    if args.precision == "fp64" and not args.no_fast:
+        f_steps = max(1, min(args.steps, 50))
+        f_elapsed, f_step_ms, f_kernel_ms, f_info, f_image = measure(pkg.PRECISION_FP32, f_steps, min(args.warmup, 2))
+        if rank == 0:
+            d = (f_image.to(torch.float64) - image.to(torch.float64))
+            fast = {"dtype": "f32", "value": W * H * spp * f_steps / f_elapsed / 1e6, "unit": "Msamples/s", "steps": f_steps, "ms_per_step": f_elapsed / f_steps * 1e3,
+                    "launch_ms_hip_events_mean": f_kernel_ms, "rmse_vs_f64_image": float(torch.sqrt(torch.mean(d * d)).item() / 255.0),
+                    "differing_channels": float((d != 0).double().mean().item()), "max_abs_diff_8bit": int(d.abs().max().item()),
+                    "mode": "MLRT_PRECISION_FP32: f32 boxes / rects / shading / primary rays, f64 ray state and sphere quadratic; a mode of the product, "
+                            "below the reference's precision (tolerance: per-channel RMSE < 1e-3 against the f64 image)", **f_info}
 
     if rank == 0:
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
         my_samples = len(my_rows) * W * spp
-        achieved = ALGO_BYTES_PER_SAMPLE * my_samples / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": "Msamples/sec (pixels*spp) --world=random 1200x800 spp=500",
-            "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "metric": cfg["metric"], "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
-            "config": {"workload": "--world=random --seed=42 --aspect_ratio=3:2 --image_width=1200 --samples_per_pixel=500 (BASELINE.json configs[1])",
+            "dtype": head_dtype, "data": "synthetic",
+            "config": {"workload": "--world=%s --seed=%d --aspect_ratio=%s --image_width=%d --samples_per_pixel=%d%s (BASELINE.json %s)"
+                                   % (cfg["world"], cfg["seed"], cfg["aspect_ratio"], W, spp,
+                                      "" if not cfg["aperture"] else " --aperture=%g --focus_dist=%g" % (cfg["aperture"], cfg["focus_dist"]), cfg["baseline"]),
+                       "precision_mode": "MLRT_PRECISION_FP64 (f64 arithmetic in the reference's operation order; device-built SAH culling structure)" if head_dtype == "f64" else "MLRT_PRECISION_FP32",
                        "rows_per_rank": len(my_rows), "row_tiling": "round-robin rows, one gather", "rng": "philox4x32-10 per (pixel, sample)",
-                       "kernel_ms_last_launch": kernel_ms, "step_ms_hip_events": step_ms_events, **renderer.info()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
-                         "hbm_physical_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                         "note": "algorithmic bytes of the REFERENCE traversal (reference BVH topology, SURVEY.md 8d) per sample x samples/s: "
-                                 "the scene is LDS resident and the device BVH is SAH-built, so this is not physical HBM utilisation and can exceed 1"},
+                       "launch_ms_hip_events_mean": kernel_ms, "launch_ms_hip_events_median": float(np.median(step_ms)),
+                       "launch_ms_hip_events_min_max": [float(min(step_ms)), float(max(step_ms))], **info},
         }
+        cpu = None
         if world_size == 1 and not args.no_cpu_baseline:
             cam19 = list(cam.origin) + list(cam.lower_left_corner) + list(cam.horizontal) + list(cam.vertical) + list(cam.u) + list(cam.v) + [cam.lens_radius]
-            out["cpu_baseline"] = cpu_baseline(pkg, cam19)
+            cpu = cpu_baseline(cfg, cam19, H)
+        out["roofline"] = roofline(args.config, head_dtype, my_samples, kernel_ms, cpu["stats_per_sample"] if cpu else None, spp)
+        if fast:
+            fr = roofline(args.config, "f32", my_samples, fast["launch_ms_hip_events_mean"], None, spp)
+            fast["roofline"] = {k: fr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "lane_utilisation", "profile") if k in fr}
+            out["fast"] = fast
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    renderer.close()
     world.close()
     if world_size > 1:
         dist.barrier()

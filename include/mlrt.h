@@ -49,8 +49,9 @@ enum { MLRT_BG_BLACK = 0, MLRT_BG_GRADIENT = 1 };
 /* arithmetic of the device path */
 enum { MLRT_PRECISION_FP32 = 0,       /* fast path: f32 boxes/rects/shading, f64 ray state and sphere quadratic */
        MLRT_PRECISION_FP64 = 1,       /* reference precision (src/vec.rs:5-8): every operation that decides a sample's value is f64
-                                       * in the reference's operation order; the culling structure (SAH BVH, box wrappers,
-                                       * primary candidate lists) is the device's own and cannot change a closest hit */
+                                       * in the reference's operation order; the culling structure (SAH BVH, conservative
+                                       * bounding-box tests, primary candidate lists) is the device's own and cannot change a
+                                       * closest hit: colour sums bit-equal to MLRT_PRECISION_FP64_STRICT (tested) */
        MLRT_PRECISION_FP64_STRICT = 2 /* as FP64, plus the reference's BVH topology and AABB::hit arithmetic (bhv.rs:29-42,
                                        * 122-165): exactly the tests the reference performs.  A test instrument (slow). */ };
 
@@ -184,6 +185,9 @@ typedef struct mlrt_options {
     int32_t primary_lists; /* 1: per-pixel-group candidate lists for primary rays (sphere-only scenes) */
     int32_t lds_scene;     /* 1: stage the packed scene in LDS when it fits */
     int32_t force_full;    /* 1: always the FULL kernel variant */
+    int32_t cull_f64;      /* MLRT_PRECISION_FP64 only. 0 (default): the culling entries are f32, moved outward with a proven error
+                            * bound, the primitives' f64 parameters sit behind them; 1: f64 entries, culling arithmetic in f64 too
+                            * (twice the LDS traffic per traversal step; same colour sums, tested) */
     int32_t tile_samples;  /* samples per big tile, >= 64 (default 512) */
     int32_t tile_queues;   /* tile sub-queues, a power of two <= 64 (default 8) */
     int32_t n_tail;        /* -1: adaptive tapering passes; else the number of entries of tail[] */
@@ -193,7 +197,7 @@ typedef struct mlrt_options {
 } mlrt_options;
 void mlrt_options_default(mlrt_options* out);
 /* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,
- * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL):
+ * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_CULL_F64, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL):
  * the only place the library reads its environment. */
 void mlrt_options_from_env(mlrt_options* out);
 

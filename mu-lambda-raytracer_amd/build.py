@@ -36,6 +36,10 @@ if DEBUG:
     os.environ.setdefault("MLRT_BLOCK", "768")
     os.environ.setdefault("MLRT_FULL_WAVES", "3")
 BLOCK = os.environ.get("MLRT_BLOCK", "1024")
+# workgroup shapes of the f64 product builds: FULL block / LEAN block / LEAN waves per SIMD / FULL waves per SIMD
+F64_SHAPE = ["-DMLRT_BLOCK=" + os.environ.get("MLRT_BLOCK64", "512"), "-DMLRT_LEAN_BLOCK=" + os.environ.get("MLRT_LEAN_BLOCK64", "1024"),
+             "-DMLRT_LEAN_WAVES_PER_EU=" + os.environ.get("MLRT_LEAN_WAVES64", "4"), "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES64", "2")]
+F64C_SHAPE = ["-DMLRT_BLOCK=512", "-DMLRT_LEAN_BLOCK=1024", "-DMLRT_LEAN_WAVES_PER_EU=4", "-DMLRT_FULL_WAVES_PER_EU=2"]
 OBJ_DIR = os.path.join(HERE, "lib", "obj" + TAG)
 LIB = os.path.join(LIB_DIR, "libmlrt_hip%s.so" % TAG)
 
@@ -46,14 +50,14 @@ UNITS = [
     # Both kernel builds pin FMA contraction OFF: every f32/f64 operation is the IEEE operation the source spells out
     # (the f64 geometry code fuses explicitly, see dfma), so the image does not depend on the compiler's inlining or on
     # which kernel variant runs.  Measured cost against -ffp-contract=fast: 1.5 % (C2) to 3.5 % (final_scene).
-    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
-    # reference-precision build (product mode): every rounding of a sample's arithmetic where the reference has it; big
-    # persistent workgroups, LDS-resident scene
-    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_SUFFIX=f64", "-DMLRT_BLOCK=" + os.environ.get("MLRT_BLOCK64", "512"),
-                              "-DMLRT_LEAN_BLOCK=" + os.environ.get("MLRT_LEAN_BLOCK64", "1024"), "-DMLRT_LEAN_WAVES_PER_EU=" + os.environ.get("MLRT_LEAN_WAVES64", "4"),
-                              "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES64", "2"), "-ffp-contract=off"] + EXTRA_KERNEL_FLAGS64 + DEBUG_FLAGS),
+    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
+    # reference-precision build (product mode): every rounding of a sample's arithmetic where the reference has it; f32
+    # culling entries with the primitives' f64 parameters in payload slots; big persistent workgroups, LDS-resident scene
+    ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f64"] + F64_SHAPE + ["-ffp-contract=off"] + EXTRA_KERNEL_FLAGS64 + DEBUG_FLAGS),
+    # the same with f64 culling entries (mlrt_options.cull_f64)
+    ("kernel_f64c.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=double", "-DMLRT_SUFFIX=f64c"] + F64C_SHAPE + ["-ffp-contract=off"] + DEBUG_FLAGS),
     # strict build (test instrument): additionally the reference's BVH topology and slab arithmetic
-    ("kernel_f64s.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256",
+    ("kernel_f64s.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256",
                                "-DMLRT_LEAN_WAVES_PER_EU=1", "-DMLRT_FULL_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),

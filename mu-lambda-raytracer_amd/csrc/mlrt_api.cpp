@@ -29,6 +29,7 @@ extern "C" {
 MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
 MLRT_DECLARE_BUILD(f64s)
+MLRT_DECLARE_BUILD(f64c)
 }
 
 namespace mlrt {
@@ -47,7 +48,7 @@ struct KernelBuild {
     int (*occupancy)(int, int, size_t);
 };
 #define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx}
-const KernelBuild kBuilds[3] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s)};  // indexed by MLRT_PRECISION_*
+const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
     int32_t code;
@@ -57,17 +58,6 @@ struct Fail {
     do { if (!(cond)) throw Fail{MLRT_ERR_INVALID, std::string(text)}; } while (0)
 #define MLRT_HIP(call) \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) throw Fail{MLRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)}; } while (0)
-
-template <typename R>
-struct Packed {
-    std::vector<DNode<R>> nodes;
-    std::vector<DMaterial<R>> materials;
-    std::vector<DTexture<R>> textures;
-    std::vector<R> perlin_vec;
-    std::vector<uint16_t> perlin_perm;
-    std::vector<unsigned char> blob;
-    int32_t off_nodes = 0, off_materials = 0, off_textures = 0, off_perlin_vec = 0, off_perlin_perm = 0;
-};
 
 void validate(const mlrt_scene& s) {
     MLRT_REQUIRE(s.n_objects > 0 && s.objects, "scene has no objects");
@@ -145,85 +135,34 @@ bool texture_needs_uv(const mlrt_scene& s, int32_t tex, int depth) {
     return false;
 }
 
+// ---- packing -----------------------------------------------------------------------------------------------------
+// R = the entries' type (mlrt_device.hpp: f32 entries with payload slots, or f64 entries), M = the type of materials,
+// textures and Perlin tables (= the arithmetic of the build).
+enum class Round { EXACT, OUTWARD, RIGOROUS };
+// Box bounds in the entry's precision, moved OUTWARD so the culling test stays conservative.  f32 entries: rounded away
+// from the box (RIGOROUS - the product f64 build, whose culling may never reject what an f64 primitive test accepts - one
+// more ulp, so that a bound that happens to be exact in f32 still clears the f64 rounding of the primitive's own arithmetic).
+// f64 entries (where the conversion is exact): 1e-12 relative - the cull_f64 product build tests them by reciprocal + fma, a few
+// 1e-16 away from the division the primitive tests use.  EXACT (strict build): the reference's own bounds, untouched.
 template <typename R>
-DNode<R> leaf_node(const mlrt_scene& s, const mlrt_prim_ref& p) {
-    DNode<R> n{};
-    if (p.kind == MLRT_PRIM_SPHERE) {
-        const mlrt_sphere& sp = s.spheres[p.index];
-        n.v[0] = (R)sp.center[0]; n.v[1] = (R)sp.center[1]; n.v[2] = (R)sp.center[2]; n.v[3] = (R)sp.radius;
-        n.link = sp.material; n.tag = TAG_SPHERE;
-    } else if (p.kind == MLRT_PRIM_BOX) {
-        const mlrt_box& b = s.boxes[p.index];
-        for (int k = 0; k < 3; k++) { n.v[k] = (R)b.min[k]; n.v[3 + k] = (R)b.max[k]; }
-        n.link = b.material; n.tag = TAG_BOX;
-    } else {
-        const mlrt_rect& r = s.rects[p.index];
-        n.v[0] = (R)r.a0_v0; n.v[1] = (R)r.a0_v1; n.v[2] = (R)r.a1_v0; n.v[3] = (R)r.a1_v1; n.v[4] = (R)r.plane;
-        n.link = r.material;
-        n.tag = TAG_RECT | (r.a0 << 4) | (r.a1 << 6) | ((3 - r.a0 - r.a1) << 8);
-    }
-    return n;
-}
-
-// Box bounds in the entry's precision, moved OUTWARD so the culling test stays conservative: f32 entries by rounding
-// away from the box, f64 entries (where the conversion is exact) by 1e-12 relative - the product f64 build tests them by
-// reciprocal + fma, a few 1e-16 away from the division the primitive tests use.  `exact` (strict build): the reference's
-// own bounds, untouched.
-template <typename R>
-R round_down(double x, bool exact = false) {
+R round_down(double x, Round mode) {
     R f = (R)x;
-    if (exact) return f;
+    if (mode == Round::EXACT) return f;
     if (sizeof(R) == 8) return (R)(x - 1e-12 * (1.0 + std::fabs(x)));
     if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<R>::infinity());
+    if (mode == Round::RIGOROUS) f = std::nextafter(f, -std::numeric_limits<R>::infinity());
     return f;
 }
 template <typename R>
-R round_up(double x, bool exact = false) {
+R round_up(double x, Round mode) {
     R f = (R)x;
-    if (exact) return f;
+    if (mode == Round::EXACT) return f;
     if (sizeof(R) == 8) return (R)(x + 1e-12 * (1.0 + std::fabs(x)));
     if ((double)f < x) f = std::nextafter(f, std::numeric_limits<R>::infinity());
+    if (mode == Round::RIGOROUS) f = std::nextafter(f, std::numeric_limits<R>::infinity());
     return f;
 }
 
-// Depth-first emission with skip links.  `budget` guards against cyclic child references.  With `wrap_leaves` a
-// sphere leaf is preceded by an inner entry holding the sphere's own bounds (skip = past the sphere): a ray that
-// misses those bounds cannot hit the sphere, so the closest hit is unchanged while most f64 sphere tests are culled.
-template <typename R>
-void emit_subtree(const mlrt_scene& s, int32_t child, std::vector<DNode<R>>& out, int& budget, bool wrap_leaves) {
-    MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
-    if (child < 0) {
-        const mlrt_prim_ref& p = s.prim_refs[~child];
-        if (wrap_leaves && p.kind == MLRT_PRIM_SPHERE) {
-            const mlrt_sphere& sp = s.spheres[p.index];
-            DNode<R> w{};
-            for (int k = 0; k < 3; k++) {
-                w.v[k] = round_down<R>(std::fmin(sp.center[k] - sp.radius, sp.center[k] + sp.radius));
-                w.v[3 + k] = round_up<R>(std::fmax(sp.center[k] - sp.radius, sp.center[k] + sp.radius));
-            }
-            w.tag = TAG_INNER;
-            w.link = (int32_t)out.size() + 2;
-            out.push_back(w);
-        }
-        out.push_back(leaf_node<R>(s, p));
-        return;
-    }
-    const mlrt_bvh_node& src = s.bvh_nodes[child];
-    const size_t me = out.size();
-    DNode<R> n{};
-    // (wrap_leaves is off exactly in the strict build: the reference's bounds as they are)
-    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(src.bounds_min[k], !wrap_leaves); n.v[3 + k] = round_up<R>(src.bounds_max[k], !wrap_leaves); }
-    n.tag = TAG_INNER;
-    out.push_back(n);
-    emit_subtree<R>(s, src.left, out, budget, wrap_leaves);
-    emit_subtree<R>(s, src.right, out, budget, wrap_leaves);
-    out[me].link = (int32_t)out.size();
-}
-
-// ---- device-side BVH quality (fast build) -------------------------------------------------------------------
-// The closest hit does not depend on the BVH's topology, so the fast build is free to replace the reference's
-// random-axis median split (bhv.rs:122-145, kept for the scene RNG replay on the host and used as-is by the parity
-// build) with a surface-area-heuristic tree over the same primitives: fewer box tests per ray, same image.
 struct Bounds {
     double lo[3], hi[3];
     void grow(const Bounds& b) { for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], b.lo[k]); hi[k] = std::fmax(hi[k], b.hi[k]); } }
@@ -247,14 +186,126 @@ bool prim_bounds(const mlrt_scene& s, const mlrt_prim_ref& p, Bounds& b) {
     b.lo[r.a0] = r.a0_v0; b.hi[r.a0] = r.a0_v1; b.lo[r.a1] = r.a1_v0; b.hi[r.a1] = r.a1_v1; b.lo[ap] = r.plane - pad; b.hi[ap] = r.plane + pad;
     return true;
 }
+
+// The entry array under construction.  Links of entries marked `reloc` are indices relative to the start of the array they
+// were emitted into (a sub-array is appended to the world with append()); payload slots are raw bytes and never touched.
 template <typename R>
-DNode<R> box_entry(const Bounds& b, int32_t skip) {
-    DNode<R> n{};
-    for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(b.lo[k]); n.v[3 + k] = round_up<R>(b.hi[k]); }
-    n.tag = TAG_INNER;
-    n.link = skip;
-    return n;
+struct Entries {
+    static constexpr bool kCull32 = sizeof(R) == 4;
+    std::vector<DNode<R>> nodes;
+    std::vector<uint8_t> reloc;
+    std::vector<int32_t> spheres;  // indices of the sphere entries (the candidate pre-pass scans these)
+    bool payload_all = false;      // product f64 build over f32 entries
+    Round round = Round::OUTWARD;
+
+    int32_t size() const { return (int32_t)nodes.size(); }
+    int32_t push(const DNode<R>& n, bool relocatable) { nodes.push_back(n); reloc.push_back(relocatable ? 1 : 0); return size() - 1; }
+    void payload(const double* v, int count) {  // f32 entries only: `count` doubles into ceil(count / 4) raw slots
+        static_assert(sizeof(DNode<float>) == 4 * sizeof(double), "a payload slot holds four doubles");
+        for (int k0 = 0; k0 < count; k0 += 4) {
+            double four[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4 && k0 + k < count; k++) four[k] = v[k0 + k];
+            DNode<R> raw;
+            std::memcpy(static_cast<void*>(&raw), four, sizeof raw <= sizeof four ? sizeof raw : sizeof four);
+            push(raw, false);
+        }
+    }
+    DNode<R> box_entry(const Bounds& b, int32_t skip) const {
+        DNode<R> n{};
+        for (int k = 0; k < 3; k++) { n.v[k] = round_down<R>(b.lo[k], round); n.v[3 + k] = round_up<R>(b.hi[k], round); }
+        n.tag = TAG_INNER;
+        n.link = skip;
+        return n;
+    }
+    // One primitive.  `wrap`: with a culling box (an inner entry) in front; Block entries are never wrapped: the step tests
+    // their own bounds.
+    void leaf(const mlrt_scene& s, const mlrt_prim_ref& p, bool wrap) {
+        Bounds pb = empty_bounds();
+        prim_bounds(s, p, pb);
+        if (p.kind == MLRT_PRIM_SPHERE) {
+            const mlrt_sphere& sp = s.spheres[p.index];
+            const double v[4] = {sp.center[0], sp.center[1], sp.center[2], sp.radius};
+            if (payload_all) {
+                // (a sphere leaf fused with its box into one entry was tried: one entry less to step over, ~4 instructions more
+                // in every step: -2 % on C2 in the product f64 build, -3.5 % in the fast build)
+                if (wrap) push(box_entry(pb, size() + 3), true);
+                DNode<R> n{};
+                n.link = sp.material; n.tag = TAG_SPHERE;
+                spheres.push_back(push(n, false));
+                payload(v, 4);
+            } else {
+                if (wrap) push(box_entry(pb, size() + 2), true);
+                DNode<R> n{};
+                for (int k = 0; k < 4; k++) n.v[k] = (R)v[k];
+                n.link = sp.material; n.tag = TAG_SPHERE;
+                spheres.push_back(push(n, false));
+            }
+        } else if (p.kind == MLRT_PRIM_BOX) {
+            const mlrt_box& b = s.boxes[p.index];
+            const double v[6] = {b.min[0], b.min[1], b.min[2], b.max[0], b.max[1], b.max[2]};
+            DNode<R> n{};
+            if (payload_all) n = box_entry(pb, 0);  // outward bounds for the step's culling test; the faces are in the payload
+            else for (int k = 0; k < 6; k++) n.v[k] = (R)v[k];
+            n.link = b.material; n.tag = TAG_BOX;
+            push(n, false);
+            if (payload_all) payload(v, 6);
+        } else {
+            const mlrt_rect& r = s.rects[p.index];
+            const double v[5] = {r.a0_v0, r.a0_v1, r.a1_v0, r.a1_v1, r.plane};
+            if (wrap) push(box_entry(pb, size() + 1 + entry_slots(TAG_RECT, kCull32, payload_all)), true);
+            DNode<R> n{};
+            if (!payload_all) for (int k = 0; k < 5; k++) n.v[k] = (R)v[k];
+            n.link = r.material;
+            n.tag = TAG_RECT | (r.a0 << 4) | (r.a1 << 6) | ((3 - r.a0 - r.a1) << 8);
+            push(n, false);
+            if (payload_all) payload(v, 5);
+        }
+    }
+    void append(const Entries<R>& body) {
+        const int32_t base = size();
+        for (size_t i = 0; i < body.nodes.size(); i++) {
+            DNode<R> e = body.nodes[i];
+            if (body.reloc[i]) e.link += base;
+            push(e, false);
+        }
+        for (int32_t sidx : body.spheres) spheres.push_back(sidx + base);
+    }
+};
+
+template <typename R, typename M>
+struct Packed {
+    Entries<R> entries;
+    std::vector<DMaterial<M>> materials;
+    std::vector<DTexture<M>> textures;
+    std::vector<M> perlin_vec;
+    std::vector<uint16_t> perlin_perm;
+    std::vector<uint16_t> sphere_index;
+    std::vector<unsigned char> blob;
+    int32_t off_nodes = 0, off_materials = 0, off_textures = 0, off_perlin_vec = 0, off_perlin_perm = 0, off_sphere_index = 0;
+};
+
+// Depth-first emission of the REFERENCE topology with skip links.  `budget` guards against cyclic child references.
+template <typename R>
+void emit_subtree(const mlrt_scene& s, int32_t child, Entries<R>& out, int& budget, bool wrap_leaves) {
+    MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
+    if (child < 0) {
+        const mlrt_prim_ref& p = s.prim_refs[~child];
+        out.leaf(s, p, wrap_leaves && p.kind == MLRT_PRIM_SPHERE);
+        return;
+    }
+    const mlrt_bvh_node& src = s.bvh_nodes[child];
+    Bounds b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = src.bounds_min[k]; b.hi[k] = src.bounds_max[k]; }
+    const int32_t me = out.push(out.box_entry(b, 0), true);
+    emit_subtree<R>(s, src.left, out, budget, wrap_leaves);
+    emit_subtree<R>(s, src.right, out, budget, wrap_leaves);
+    out.nodes[(size_t)me].link = out.size();
 }
+
+// ---- device-side BVH quality -----------------------------------------------------------------------------------------
+// The closest hit does not depend on the BVH's topology, so every build but the strict one is free to replace the
+// reference's random-axis median split (bhv.rs:122-145, kept for the scene RNG replay on the host and used as-is by the strict
+// build) with a surface-area-heuristic tree over the same primitives: fewer box tests per ray, same image.
 void collect_leaves(const mlrt_scene& s, int32_t child, std::vector<int32_t>& refs, int& budget) {
     MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
     if (child < 0) { refs.push_back(~child); return; }
@@ -268,12 +319,11 @@ struct SahItem {
 };
 // Emits the SAH subtree over items[begin, end) in threaded order; returns its bounds.
 template <typename R>
-Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, size_t end, std::vector<DNode<R>>& out, bool wrap_leaves) {
+Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, size_t end, Entries<R>& out, bool wrap_leaves) {
     const size_t n = end - begin;
     if (n == 1) {
         const mlrt_prim_ref& p = s.prim_refs[items[begin].ref];
-        if (wrap_leaves && p.kind != MLRT_PRIM_BOX) out.push_back(box_entry<R>(items[begin].b, (int32_t)out.size() + 2));
-        out.push_back(leaf_node<R>(s, p));
+        out.leaf(s, p, wrap_leaves && p.kind != MLRT_PRIM_BOX);
         return items[begin].b;
     }
     int best_axis = 0;
@@ -292,8 +342,7 @@ Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, 
         }
     }
     std::sort(items.begin() + begin, items.begin() + end, [best_axis](const SahItem& a, const SahItem& b) { return a.c[best_axis] < b.c[best_axis]; });
-    const size_t me = out.size();
-    out.push_back(DNode<R>{});
+    const int32_t me = out.push(DNode<R>{}, true);
     // Child order of the threaded walk: the child with the larger surface first (the likelier one to shrink the hit
     // distance early; measured against input order, smaller-first and nearer-to-the-eye-first in round 1).
     Bounds lb = empty_bounds(), rb = empty_bounds();
@@ -306,7 +355,7 @@ Bounds emit_sah(const mlrt_scene& s, std::vector<SahItem>& items, size_t begin, 
     }
     Bounds b = emit_sah<R>(s, items, begin, best_split, out, wrap_leaves);
     b.grow(emit_sah<R>(s, items, best_split, end, out, wrap_leaves));
-    out[me] = box_entry<R>(b, (int32_t)out.size());
+    out.nodes[(size_t)me] = out.box_entry(b, out.size());
     return b;
 }
 // World-space bounds of `b` under Translate(offset, Rotate(axis, angle, .)): the 8 rotated corners, then the offset.
@@ -339,18 +388,22 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
     return off;
 }
 
-// `fast`: SAH device BVHs, bounding-box wrappers around sphere leaves and around the top-level entries whose miss a
-// box can prove (primitives, medium boundaries, whole transform brackets).  None of it changes a closest hit or the
-// conditions under which a medium draws (a ray that misses the boundary's box misses the boundary: volumes.rs:27-34
-// returns None before drawing).  The parity build packs the reference structure verbatim.
-template <typename R>
-Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
-    Packed<R> P;
+// `wraps`: bounding-box entries in front of sphere leaves and in front of the top-level
+// entries whose miss a box can prove (primitives, medium boundaries, whole transform brackets); `sah`: SAH device BVHs.
+// None of it changes a closest hit or the conditions under which a medium draws (a ray that misses the boundary's box
+// misses the boundary: volumes.rs:27-34 returns None before drawing).  The strict build packs the reference structure
+// verbatim (wraps = sah = false, Round::EXACT).
+template <typename R, typename M>
+Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool sah, bool solid_only, bool payload_all, Round round) {
+    Packed<R, M> P;
+    constexpr bool kCull32 = sizeof(R) == 4;
+    P.entries.payload_all = payload_all; P.entries.round = round;
     for (int i = 0; i < s.n_objects; i++) {
         const mlrt_object& src = s.objects[i];
         const bool xf = src.transform >= 0 && (s.transforms[src.transform].has_translate || s.transforms[src.transform].has_rotate);
-        // contents in object space, emitted into a scratch list first so a wrapper can be put in front
-        std::vector<DNode<R>> body;
+        // contents in object space, emitted into a scratch array first so a wrapper can be put in front
+        Entries<R> body;
+        body.payload_all = payload_all; body.round = round;
         Bounds bounds = empty_bounds();
         bool bounded = false;  // `bounds` encloses everything a ray can interact with inside this object
         if (src.kind == MLRT_OBJ_BVH) {
@@ -358,8 +411,8 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
             if (root == MLRT_BVH_EMPTY) {
                 DNode<R> e{};
                 e.tag = TAG_EMPTY;
-                body.push_back(e);
-            } else if (fast && sah) {
+                body.push(e, false);
+            } else if (sah) {
                 std::vector<int32_t> refs;
                 int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
                 collect_leaves(s, root, refs, budget);
@@ -369,79 +422,79 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
                     prim_bounds(s, s.prim_refs[refs[k]], items[k].b);
                     for (int a = 0; a < 3; a++) items[k].c[a] = 0.5 * (items[k].b.lo[a] + items[k].b.hi[a]);
                 }
-                bounds = emit_sah<R>(s, items, 0, items.size(), body, true);
+                bounds = emit_sah<R>(s, items, 0, items.size(), body, wraps);
                 bounded = true;
             } else {
                 int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
-                emit_subtree<R>(s, root, body, budget, fast);
+                emit_subtree<R>(s, root, body, budget, wraps);
                 if (root >= 0) { for (int k = 0; k < 3; k++) { bounds.lo[k] = s.bvh_nodes[root].bounds_min[k]; bounds.hi[k] = s.bvh_nodes[root].bounds_max[k]; } bounded = true; }
                 else bounded = prim_bounds(s, s.prim_refs[~root], bounds);
             }
         } else if (src.kind == MLRT_OBJ_PRIM) {
-            body.push_back(leaf_node<R>(s, src.prim));
+            body.leaf(s, src.prim, false);
             bounded = prim_bounds(s, src.prim, bounds);
         } else {  // ConstantMedium: the medium entry, then its boundary primitive
             DNode<R> e{};
-            e.v[0] = (R)src.neg_inv_density;
+            if (!payload_all) e.v[0] = (R)src.neg_inv_density;
             e.link = src.phase_material;
             e.tag = TAG_MEDIUM;
-            body.push_back(e);
-            body.push_back(leaf_node<R>(s, src.prim));
+            body.push(e, false);
+            if (payload_all) body.payload(&src.neg_inv_density, 1);
+            body.leaf(s, src.prim, false);
             bounded = prim_bounds(s, src.prim, bounds);
         }
-        // links inside `body` are relative to its start: rebase them when appending
-        const bool wrap = fast && bounded && !(src.kind == MLRT_OBJ_PRIM && src.prim.kind == MLRT_PRIM_BOX && !xf);
-        const int32_t n_pre = (wrap ? 1 : 0) + (xf ? 1 : 0);
-        const int32_t base = (int32_t)P.nodes.size() + n_pre;
-        const int32_t after = base + (int32_t)body.size() + (xf ? 1 : 0);
+        const bool wrap = wraps && bounded && !(src.kind == MLRT_OBJ_PRIM && src.prim.kind == MLRT_PRIM_BOX && !xf);
+        const int32_t xf_slots = xf ? entry_slots(TAG_XFORM, kCull32, payload_all) : 0;
+        const int32_t after = P.entries.size() + (wrap ? 1 : 0) + xf_slots + body.size() + (xf ? 1 : 0);
         if (wrap) {
             Bounds wb = xf ? transform_bounds(s.transforms[src.transform], bounds) : bounds;
             pad_bounds(wb, 1e-6);
-            P.nodes.push_back(box_entry<R>(wb, after));  // world-space box in front of everything this object emits
+            P.entries.push(P.entries.box_entry(wb, after), false);  // world-space box in front of everything this object emits
         }
         if (xf) {  // Translate(offset, Rotate(axis, angle, .)) opens: the cursor's ray moves to object space
             const mlrt_transform& t = s.transforms[src.transform];
+            const double v[5] = {t.has_rotate ? t.sin_theta : 0.0, t.has_rotate ? t.cos_theta : 1.0, t.has_translate ? t.offset[0] : 0.0,
+                                 t.has_translate ? t.offset[1] : 0.0, t.has_translate ? t.offset[2] : 0.0};
             DNode<R> e{};
-            e.v[0] = (R)(t.has_rotate ? t.sin_theta : 0.0);
-            e.v[1] = (R)(t.has_rotate ? t.cos_theta : 1.0);
-            for (int k = 0; k < 3; k++) e.v[2 + k] = (R)(t.has_translate ? t.offset[k] : 0.0);
+            if (!payload_all) for (int k = 0; k < 5; k++) e.v[k] = (R)v[k];
             e.tag = TAG_XFORM | ((t.has_translate ? XF_TRANSLATE : 0) << 4) | ((t.has_rotate ? XF_ROTATE : 0) << 4) | ((t.has_rotate ? t.axis : 0) << 8);
-            P.nodes.push_back(e);
+            P.entries.push(e, false);
+            if (payload_all) P.entries.payload(v, 5);
         }
-        for (DNode<R> e : body) {
-            if ((e.tag & TAG_KIND_MASK) == TAG_INNER) e.link += base;
-            P.nodes.push_back(e);
-        }
+        P.entries.append(body);
         if (xf) {
             DNode<R> e{};
             e.tag = TAG_XFORM_END;
-            P.nodes.push_back(e);
+            P.entries.push(e, false);
         }
+        MLRT_REQUIRE(P.entries.size() == after, "internal error: entry count of an object");
     }
     for (int i = 0; i < s.n_materials; i++) {
         const mlrt_material& m = s.materials[i];
-        DMaterial<R> d{};
-        d.kind = m.kind | (texture_needs_uv(s, m.texture, 0) ? MATFLAG_NEEDS_UV : 0);
-        if (m.texture >= 0 && s.textures[m.texture].kind == MLRT_TEX_NOISE && (m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC)) d.kind |= MATFLAG_NOISE;
-        d.tex = m.texture;
-        for (int k = 0; k < 3; k++) d.albedo[k] = (R)m.albedo[k];
+        const bool textured = m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC;
+        const int32_t tex = textured ? m.texture : -1;  // (Metal / Dielectric never sample a texture, whatever the caller left in the field)
+        DMaterial<M> d{};
+        d.kind = m.kind | (texture_needs_uv(s, tex, 0) ? MATFLAG_NEEDS_UV : 0);
+        if (tex >= 0 && s.textures[tex].kind == MLRT_TEX_NOISE) d.kind |= MATFLAG_NOISE;
+        d.tex = tex;
+        for (int k = 0; k < 3; k++) d.albedo[k] = (M)m.albedo[k];
         // a scene whose textures are all SolidColor (the LEAN kernel variant) carries the colour in the material and no
         // texture table: 32 bytes per texture less in LDS and no dependent texture load in the shading code
-        if (solid_only && m.texture >= 0 && (m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC))
-            for (int k = 0; k < 3; k++) d.albedo[k] = (R)s.textures[m.texture].color[k];
-        d.param = (R)m.param;
+        if (solid_only && tex >= 0)
+            for (int k = 0; k < 3; k++) d.albedo[k] = (M)s.textures[tex].color[k];
+        d.param = (M)m.param;
         P.materials.push_back(d);
     }
     for (int i = 0; i < s.n_textures && !solid_only; i++) {
         const mlrt_texture& t = s.textures[i];
-        DTexture<R> d{};
+        DTexture<M> d{};
         d.kind = t.kind; d.a = t.index; d.b = t.index2;
-        for (int k = 0; k < 3; k++) d.color[k] = (R)t.color[k];
-        d.scale = (R)t.scale;
+        for (int k = 0; k < 3; k++) d.color[k] = (M)t.color[k];
+        d.scale = (M)t.scale;
         P.textures.push_back(d);
     }
     for (int i = 0; i < s.n_perlins; i++) {
-        for (int k = 0; k < 3072; k++) P.perlin_vec.push_back((R)s.perlins[i].ranvec[k]);
+        for (int k = 0; k < 3072; k++) P.perlin_vec.push_back((M)s.perlins[i].ranvec[k]);
         for (int k = 0; k < 3072; k++) {
             const int32_t v = s.perlins[i].perm[k];
             MLRT_REQUIRE(v >= 0 && v < 1024, "perlin permutation entry out of range");
@@ -451,14 +504,17 @@ Packed<R> pack(const mlrt_scene& s, bool fast, bool sah, bool solid_only) {
     {   // sentinel: skip links that leave the array point here (index = number of real entries)
         DNode<R> end{};
         end.tag = TAG_END;
-        end.link = (int32_t)P.nodes.size();
-        P.nodes.push_back(end);
+        end.link = P.entries.size();
+        P.entries.push(end, false);
     }
-    P.off_nodes = append(P.blob, P.nodes);
+    // (the candidate pre-pass exists for sphere-only scenes, primary_lists_wanted(): no list otherwise - final_scene's blob just fits the LDS)
+    if (solid_only && P.entries.size() <= 65536) for (int32_t e : P.entries.spheres) P.sphere_index.push_back((uint16_t)e);
+    P.off_nodes = append(P.blob, P.entries.nodes);
     P.off_materials = append(P.blob, P.materials);
     P.off_textures = append(P.blob, P.textures);
     P.off_perlin_vec = append(P.blob, P.perlin_vec);
     P.off_perlin_perm = append(P.blob, P.perlin_perm);
+    P.off_sphere_index = append(P.blob, P.sphere_index);
     while (P.blob.size() % 16) P.blob.push_back(0);
     return P;
 }
@@ -475,8 +531,8 @@ struct mlrt_context {
     int32_t n_cus = 0;
     unsigned char* d_blob = nullptr;
     int32_t blob_bytes = 0;
-    int32_t off[5] = {0, 0, 0, 0, 0};
-    int32_t n_nodes = 0;
+    int32_t off[6] = {0, 0, 0, 0, 0, 0};
+    int32_t n_nodes = 0, n_sphere_index = 0;
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
@@ -590,6 +646,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.blob = c->d_blob; K.blob_bytes = c->blob_bytes;
     K.off_nodes = c->off[0]; K.off_materials = c->off[1]; K.off_textures = c->off[2];
     K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
+    K.off_sphere_index = c->off[5]; K.n_sphere_index = c->n_sphere_index;
     K.n_nodes = c->n_nodes;
     K.images = c->d_images;
     for (int k = 0; k < 3; k++) {
@@ -732,7 +789,7 @@ int32_t mlrt_device_count(void) {
 void mlrt_options_default(mlrt_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);
-    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0;
+    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0;
     o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
     o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0;
 }
@@ -745,6 +802,7 @@ void mlrt_options_from_env(mlrt_options* o) {
     if (std::getenv("MLRT_NO_PRIMARY_LISTS")) o->primary_lists = 0;
     if (std::getenv("MLRT_NO_LDS")) o->lds_scene = 0;
     if (std::getenv("MLRT_FORCE_FULL")) o->force_full = 1;
+    if (std::getenv("MLRT_CULL_F64")) o->cull_f64 = 1;
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) o->tile_samples = std::atoi(ts);
     if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) o->tile_queues = std::atoi(nq);
     if (const char* spec = std::getenv("MLRT_TILE_TAIL")) {
@@ -782,7 +840,7 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         MLRT_REQUIRE(device >= 0 && device < n_dev, "device ordinal out of range");
         c = new mlrt_context();
         c->device = device; c->precision = precision; c->opt = *options;
-        c->build = &kBuilds[precision];
+        c->build = &kBuilds[(precision == MLRT_PRECISION_FP64 && options->cull_f64) ? 3 : precision];
         const bool strict = precision == MLRT_PRECISION_FP64_STRICT;
         MLRT_HIP(hipSetDevice(device));
         hipDeviceProp_t prop;
@@ -795,19 +853,25 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         std::vector<unsigned char> blob;
         const bool solid_only = c->variant == 1;  // the LEAN kernel variant reads no texture table (its scenes have SolidColor textures only)
         c->block_threads = c->build->block_threads(c->variant);
+        auto take = [&](auto& P) {
+            blob.swap(P.blob);
+            const int32_t o[6] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm, P.off_sphere_index};
+            std::memcpy(c->off, o, sizeof o);
+            c->n_nodes = P.entries.size() - 1;  // without the sentinel
+            c->n_sphere_index = (int32_t)P.sphere_index.size();
+        };
+        const bool wraps = !strict && options->leaf_wrap != 0, sah = !strict && options->sah != 0;
         if (precision == MLRT_PRECISION_FP32) {
-            Packed<float> P = pack<float>(*scene, options->leaf_wrap != 0, options->sah != 0, solid_only);
-            blob.swap(P.blob);
-            const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
-            std::memcpy(c->off, o, sizeof o);
-            c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
+            auto P = pack<float, float>(*scene, wraps, sah, solid_only, false, Round::OUTWARD);
+            take(P);
+        } else if (precision == MLRT_PRECISION_FP64 && !options->cull_f64) {
+            // product f64: f32 culling entries (rigorously outward), every primitive's f64 parameters in payload slots
+            auto P = pack<float, double>(*scene, wraps, sah, solid_only, true, Round::RIGOROUS);
+            take(P);
         } else {
-            // product f64: the same culling structure as the fast build over f64 entries; strict: the reference's structure verbatim
-            Packed<double> P = pack<double>(*scene, !strict && options->leaf_wrap != 0, !strict && options->sah != 0, solid_only);
-            blob.swap(P.blob);
-            const int32_t o[5] = {P.off_nodes, P.off_materials, P.off_textures, P.off_perlin_vec, P.off_perlin_perm};
-            std::memcpy(c->off, o, sizeof o);
-            c->n_nodes = (int32_t)P.nodes.size() - 1;  // without the sentinel
+            // cull_f64: the same culling structure over f64 entries; strict: the reference's structure verbatim
+            auto P = pack<double, double>(*scene, wraps, sah, solid_only, false, strict ? Round::EXACT : Round::OUTWARD);
+            take(P);
         }
         c->blob_bytes = (int32_t)blob.size();
         MLRT_HIP(hipMalloc(&c->d_blob, blob.size()));

@@ -30,10 +30,20 @@ enum : int32_t {
 // TAG_XFORM entries carry XF_TRANSLATE << 4 | XF_ROTATE << 4 | axis << 8
 enum : int32_t { XF_TRANSLATE = 1, XF_ROTATE = 2 };
 
+// Two entry layouts.
+//  * f64 entries (64 B; the strict build and the cull_f64 product build): everything inline, as listed below.
+//  * f32 entries (32 B; the fast build and the product f64 build): the bounds of inner entries are f32, moved OUTWARD -
+//    they only decide what is skipped.  Fast build: the primitives' parameters are inline f32 values, as in the list below.
+//    Product f64 build: the f64 parameters of a primitive live in PAYLOAD slots (raw 32-byte slots of doubles) right behind
+//    its entry (a Block entry's own v[] holds outward f32 bounds: the step culls with them):
+//        sphere 1 slot: cx, cy, cz, radius | box 2 slots: min xyz, max xyz |
+//        rect 2 slots: a0_v0, a0_v1, a1_v0, a1_v1, plane | medium 1 slot: neg_inv_density | xform 2 slots: sin, cos, offset xyz
+//    Skip links are absolute entry indices and already account for payload slots; entry_slots() is the one rule both the
+//    packer and the kernel use to step over an entry.
 template <typename R>
 struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
     // inner    : v = bounds min xyz, max xyz              link = skip (absolute entry index)
-    // sphere   : v = cx, cy, cz, radius                   link = material
+    // sphere   : v = cx, cy, cz, radius (f64 entries)     link = material
     // box      : v = min xyz, max xyz (shapes.rs Block)   link = material
     // rect     : v = a0_v0, a0_v1, a1_v0, a1_v1, plane    link = material
     // medium   : v = neg_inv_density                      link = phase (Isotropic) material; boundary = next entry
@@ -44,6 +54,20 @@ struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
 };
 static_assert(sizeof(DNode<float>) == 32, "f32 entry must be 32 bytes (two ds_read_b128)");
 static_assert(sizeof(DNode<double>) == 64, "f64 entry is one 64-byte line");
+
+#if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
+#define MLRT_HD __host__ __device__
+#else
+#define MLRT_HD
+#endif
+// Slots an entry occupies.  cull32 && payload_all: the product f64 build (every primitive's parameters in payload slots).
+MLRT_HD inline int32_t entry_slots(int32_t kind, bool cull32, bool payload_all) {
+    if (!cull32 || !payload_all) return 1;
+    if (kind == TAG_SPHERE) return 2;
+    if (kind == TAG_BOX || kind == TAG_RECT || kind == TAG_XFORM) return 3;
+    if (kind == TAG_MEDIUM) return 2;
+    return 1;
+}
 
 enum : int32_t { MATFLAG_NEEDS_UV = 1 << 8, MATFLAG_NOISE = 1 << 9 };  // NOISE: the material's own texture is a NoiseTexture
 
@@ -82,6 +106,7 @@ struct KParams {
     const unsigned char* blob;  // packed scene in HBM
     int32_t blob_bytes;
     int32_t off_nodes, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
+    int32_t off_sphere_index, n_sphere_index;  // u16 entry indices of the sphere entries, in entry order (the candidate pre-pass scans these)
     int32_t n_nodes;
     const DImage* images;
     // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does

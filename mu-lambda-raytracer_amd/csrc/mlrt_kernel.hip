@@ -83,6 +83,17 @@ constexpr bool kStrict = false;
 #endif
 static_assert(!(kFast && kStrict), "the strict build is an f64 build");
 constexpr bool kProduct64 = !kFast && !kStrict;
+// The entries' own type: the bounds of inner entries (and of Block entries) and the arithmetic of the
+// per-step culling test.  float: 32-byte entries, primitives' f64 parameters in payload slots (mlrt_device.hpp).
+#ifndef MLRT_CULL
+#error "compile with -DMLRT_CULL=float or -DMLRT_CULL=double"
+#endif
+typedef MLRT_CULL creal;
+constexpr bool kCull32 = sizeof(creal) == 4;
+static_assert(!kFast || kCull32, "the fast build has f32 entries");
+static_assert(!kStrict || !kCull32, "the strict build has f64 entries");
+constexpr bool kPayloadAll = kCull32 && !kFast;    // product f64 build: every primitive's parameters are f64 payload slots
+constexpr bool kRigorousCull = kCull32 && !kFast;  // ... and its f32 culling test may never reject what an f64 primitive test accepts
 // Outward slack of the product f64 build's culling tests: reciprocal + fma instead of the reference's division moves a
 // slab distance by a few 1e-16 relative; 1e-12 is far outside that and far inside anything a box can wrongly admit.
 constexpr double kCullSlack64 = 1.0 + 1e-12;
@@ -273,32 +284,51 @@ DEV V3 unit_ball_from_words(uint32_t w0, uint32_t w1, uint32_t w2) {
 
 // ---------------------------------------------------------------------------------------------- scene view
 struct Scene {
-    const DNode<real>* nodes;       // the linear threaded entry array (see mlrt_device.hpp)
+    const DNode<creal>* nodes;      // the linear threaded entry array (see mlrt_device.hpp)
     const DMaterial<real>* materials;
     const DTexture<real>* textures;
     const real* perlin_vec;         // [tables][1024][3]
     const uint16_t* perlin_perm;    // [tables][3][1024]
     const DImage* images;           // HBM (L2-resident)
 };
+// The f64 parameters of the primitive whose entry is `idx` (mlrt_device.hpp: payload slots behind an f32 entry, inline in an
+// f64 entry; the fast build computes boxes, rects, media and transforms from the entry's inline f32 values).
+DEV const double* payload(const Scene& S, int idx) { return reinterpret_cast<const double*>(&S.nodes[idx + 1]); }
+struct SphereP {
+    double cx, cy, cz, r;
+};
+DEV SphereP sphere_params(const Scene& S, int idx, const DNode<creal>& n) {
+    SphereP s;
+    if (kPayloadAll) { const double* p = payload(S, idx); s.cx = p[0]; s.cy = p[1]; s.cz = p[2]; s.r = p[3]; }
+    else { s.cx = (double)n.v[0]; s.cy = (double)n.v[1]; s.cz = (double)n.v[2]; s.r = (double)n.v[3]; }
+    return s;
+}
+template <int N>
+DEV void prim_params(const Scene& S, int idx, const DNode<creal>& n, double (&out)[N]) {
+    if (kPayloadAll) {
+        const double* p = payload(S, idx);
+#pragma unroll
+        for (int k = 0; k < N; k++) out[k] = p[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) out[k] = (double)n.v[k];
+    }
+}
+DEV int slots_of(int tag) { return entry_slots(tag & TAG_KIND_MASK, kCull32, kPayloadAll); }
 
 // What the cheap per-step tests need of the ray in the current (world or object) space.
 struct SlabRay {
-    V3 of, invd;   // fast build: -(float)origin/(float)direction and 1/(float)direction; parity build: origin and direction
+    // f32 entries and the cull_f64 product build: -origin/direction and 1/direction (one fma per plane); strict build: origin and direction.
+    // of2*: product f64 build over f32 entries only - the offsets of the max planes, see slab_ray (elsewhere unused: of* serves both planes)
+    creal ofx, ofy, ofz, ix, iy, iz, of2x, of2y, of2z;
 };
-// t = (k - origin) / direction for a plane coordinate k.  Fast build: ONE explicit fma per plane, k * (1/d) + (-o/d) (the
-// explicit builtin keeps the rounding independent of the compiler's contraction setting); parity build: the reference's
-// subtraction and division (bhv.rs:33-35).
-DEV real slab_t(real k, real of, real invd) {
-    if (kFast) return (real)__builtin_fmaf((float)k, (float)invd, (float)of);
-    if (kProduct64) return (real)__builtin_fma((double)k, (double)invd, (double)of);  // culling only (see kCullSlack64)
+// t = (k - origin) / direction for a plane coordinate k.  f32 entries: ONE explicit fma per plane, k * (1/d) + (-o/d) (the
+// explicit builtin keeps the rounding independent of the compiler's contraction setting); cull_f64 product build: the same in
+// f64 (culling only, see kCullSlack64); strict build: the reference's subtraction and division (bhv.rs:33-35).
+DEV creal slab_t(creal k, creal of, creal invd) {
+    if (kCull32) return (creal)__builtin_fmaf((float)k, (float)invd, (float)of);
+    if (!kStrict) return (creal)__builtin_fma((double)k, (double)invd, (double)of);
     return (k - of) / invd;
-}
-// The reference's own t = (k - origin) / direction in every build whose `real` is f64: the distance of an ACCEPTED face hit
-// (Block = six AARects, aarects.rs:46) must not carry the culling form's rounding.
-template <bool EXACT>
-DEV real face_t(real k, real of, real invd) {
-    if (EXACT) return (k - of) / invd;
-    return slab_t(k, of, invd);
 }
 // The f64 ray for the primitive tests.
 struct Ray {
@@ -307,30 +337,43 @@ struct Ray {
     double inv_a;  // fast build: 1/|d|^2
 };
 
+// Translate(offset, Rotate(axis, angle, .)) of an XFORM entry
+struct XfP {
+    double sin_t, cos_t, ox, oy, oz;
+    int tag;
+};
+DEV XfP xform_params(const Scene& S, int idx) {
+    const DNode<creal> n = S.nodes[idx];
+    double v[5];
+    prim_params<5>(S, idx, n, v);
+    XfP x;
+    x.sin_t = v[0]; x.cos_t = v[1]; x.ox = v[2]; x.oy = v[3]; x.oz = v[4]; x.tag = n.tag;
+    return x;
+}
 // Translate::hit / Rotate::hit ray mapping (transforms.rs:33, 106-114, 128-132), in f64
-DEV P3 rotate_back(const DNode<real>& xf, P3 v) {
+DEV P3 rotate_back(const XfP& xf, P3 v) {
 #pragma clang fp contract(off)
     const int a1 = (xf.tag >> 8) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const double sin_t = (double)xf.v[0], cos_t = (double)xf.v[1];
+    const double sin_t = xf.sin_t, cos_t = xf.cos_t;
     const double v0 = compp(v, a0), v2 = compp(v, a2);
     const double n0 = dfma(cos_t, v0, -(sin_t * v2));
     const double n2 = dfma(sin_t, v0, cos_t * v2);
     return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
 }
-DEV P3 rotate_fwd(const DNode<real>& xf, P3 v) {  // transforms.rs:116-124
+DEV P3 rotate_fwd(const XfP& xf, P3 v) {  // transforms.rs:116-124
 #pragma clang fp contract(off)
     const int a1 = (xf.tag >> 8) & 3, a2 = (a1 + 1) % 3, a0 = (a1 + 2) % 3;
-    const double sin_t = (double)xf.v[0], cos_t = (double)xf.v[1];
+    const double sin_t = xf.sin_t, cos_t = xf.cos_t;
     const double v0 = compp(v, a0), v2 = compp(v, a2);
     const double n0 = dfma(cos_t, v0, sin_t * v2);
     const double n2 = dfma(-sin_t, v0, cos_t * v2);
     return mkp(a0 == 0 ? n0 : (a2 == 0 ? n2 : v.x), a0 == 1 ? n0 : (a2 == 1 ? n2 : v.y), a0 == 2 ? n0 : (a2 == 2 ? n2 : v.z));
 }
-DEV bool xf_translates(const DNode<real>& xf) { return ((xf.tag >> 4) & XF_TRANSLATE) != 0; }
-DEV bool xf_rotates(const DNode<real>& xf) { return ((xf.tag >> 4) & XF_ROTATE) != 0; }
-DEV void to_object(const DNode<real>& xf, P3& o, P3& d) {
+DEV bool xf_translates(const XfP& xf) { return ((xf.tag >> 4) & XF_TRANSLATE) != 0; }
+DEV bool xf_rotates(const XfP& xf) { return ((xf.tag >> 4) & XF_ROTATE) != 0; }
+DEV void to_object(const XfP& xf, P3& o, P3& d) {
 #pragma clang fp contract(off)
-    if (xf_translates(xf)) o = o - mkp((double)xf.v[2], (double)xf.v[3], (double)xf.v[4]);
+    if (xf_translates(xf)) o = o - mkp(xf.ox, xf.oy, xf.oz);
     if (xf_rotates(xf)) { o = rotate_back(xf, o); d = rotate_back(xf, d); }
 }
 // The ray in the space of the bracket `xf` (entry index, -1 = world).
@@ -339,7 +382,7 @@ DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
 #pragma clang fp contract(off)
     Ray r;
     r.o = o; r.d = d;
-    if ((FEAT & FEAT_XFORM) && xf >= 0) to_object(S.nodes[xf], r.o, r.d);
+    if ((FEAT & FEAT_XFORM) && xf >= 0) to_object(xform_params(S, xf), r.o, r.d);
     r.a = dfma(r.d.z, r.d.z, dfma(r.d.y, r.d.y, r.d.x * r.d.x));  // length_squared: x*x + y*y + z*z
     if (kFast) {
         // 1/|d|^2: f32 seed (1e-7) + ONE Newton step (1e-14: the roots carry that relative error, far below the f32 shading
@@ -352,86 +395,98 @@ DEV Ray local_ray(const Scene& S, int xf, P3 o, P3 d) {
     }
     return r;
 }
+// Relative slack of the f32 culling test on the far bound and on closest-so-far.  Fast build: 2-3 ulp (decisions may flip in
+// grazing cases, inside the build's RMSE tolerance).  Product f64 build: the test must NEVER reject what the f64 primitive
+// test would accept, so the slack covers the worst-case relative error of both interval ends (2 x 4 ulp/2) and the absolute
+// error is folded into the ray (slab_ray).
+constexpr float kSlack32 = kRigorousCull ? 1.000001f : 1.0000003f;
 DEV SlabRay slab_ray(const Ray& r) {
     SlabRay q;
-    q.of = to_v3(r.o);
-    if (kFast) {
+    if (kCull32) {
         // an axis-parallel ray (d = 0 on an axis) keeps finite terms: |d| is floored at 1e-30, so t stays +-1e30-sized
         // with the right sign instead of inf - inf
         const float tiny = 1e-30f;
         const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
-        q.invd = mk(fast_rcp((real)(fabsf(dx) < tiny ? copysignf(tiny, dx) : dx)), fast_rcp((real)(fabsf(dy) < tiny ? copysignf(tiny, dy) : dy)),
-                    fast_rcp((real)(fabsf(dz) < tiny ? copysignf(tiny, dz) : dz)));
-        q.of = mk(-(q.of.x * q.invd.x), -(q.of.y * q.invd.y), -(q.of.z * q.invd.z));
-    } else if (kProduct64) {
+        const float ix = fast_rcp(fabsf(dx) < tiny ? copysignf(tiny, dx) : dx), iy = fast_rcp(fabsf(dy) < tiny ? copysignf(tiny, dy) : dy),
+                    iz = fast_rcp(fabsf(dz) < tiny ? copysignf(tiny, dz) : dz);
+        const float ofx = -((float)r.o.x * ix), ofy = -((float)r.o.y * iy), ofz = -((float)r.o.z * iz);
+        q.ix = (creal)ix; q.iy = (creal)iy; q.iz = (creal)iz;
+        if (kRigorousCull) {
+            // Error of the computed t' = fma(k', r, of') against the exact (k' - o) / d with f64 o, d (k' is the entry's f32
+            // bound, already moved outward by the packer): r = 1/d (1 + dr), |dr| <= 3 * 2^-24 (d rounded to f32, v_rcp_f32 1 ulp);
+            // of' = -o (1 + do)(1 + dm) r, |do|, |dm| <= 2^-24; one rounding in the fma.  So
+            //     |t' - t| <= |t| * 4 * 2^-24  +  |o / d| * 2 * 2^-24   (+ second order).
+            // The first term is relative and covered by kSlack32.  The second is absolute and can dwarf t (an origin 1000
+            // units from the world origin, a sphere hit at t = 1): e = |o' r| * 2^-21 (4x the bound) widens the slab on
+            // this axis - the near plane's t is lowered, the far plane's raised.  t0 comes from the entry's min plane, which is
+            // the near one when r > 0: of (min plane) = of' - sign(r) e, of2 (max plane) = of' + sign(r) e.
+            const float ex = copysignf(fabsf(ofx) * 4.76837158e-7f, ix), ey = copysignf(fabsf(ofy) * 4.76837158e-7f, iy), ez = copysignf(fabsf(ofz) * 4.76837158e-7f, iz);
+            q.ofx = (creal)(ofx - ex); q.ofy = (creal)(ofy - ey); q.ofz = (creal)(ofz - ez);
+            q.of2x = (creal)(ofx + ex); q.of2y = (creal)(ofy + ey); q.of2z = (creal)(ofz + ez);
+        } else {
+            q.ofx = (creal)ofx; q.ofy = (creal)ofy; q.ofz = (creal)ofz;
+            q.of2x = q.ofx; q.of2y = q.ofy; q.of2z = q.ofz;
+        }
+    } else if (!kStrict) {
         // the same form in f64: 1/d by v_rcp_f64 + one Newton step (~1e-16; the slack is 1e-12), |d| floored at 1e-300
         const double tiny = 1e-300;
         const double dx = fabs(r.d.x) < tiny ? copysign(tiny, r.d.x) : r.d.x, dy = fabs(r.d.y) < tiny ? copysign(tiny, r.d.y) : r.d.y,
                      dz = fabs(r.d.z) < tiny ? copysign(tiny, r.d.z) : r.d.z;
         double ix = __builtin_amdgcn_rcp(dx), iy = __builtin_amdgcn_rcp(dy), iz = __builtin_amdgcn_rcp(dz);
         ix = ix * __builtin_fma(-dx, ix, 2.0); iy = iy * __builtin_fma(-dy, iy, 2.0); iz = iz * __builtin_fma(-dz, iz, 2.0);
-        q.invd = mk((real)ix, (real)iy, (real)iz);
-        q.of = mk((real)-(r.o.x * ix), (real)-(r.o.y * iy), (real)-(r.o.z * iz));
+        q.ix = (creal)ix; q.iy = (creal)iy; q.iz = (creal)iz;
+        q.ofx = (creal)-(r.o.x * ix); q.ofy = (creal)-(r.o.y * iy); q.ofz = (creal)-(r.o.z * iz);
+        q.of2x = q.ofx; q.of2y = q.ofy; q.of2z = q.ofz;
     } else {
-        q.invd = to_v3(r.d);
+        q.ofx = (creal)r.o.x; q.ofy = (creal)r.o.y; q.ofz = (creal)r.o.z;
+        q.ix = (creal)r.d.x; q.iy = (creal)r.d.y; q.iz = (creal)r.d.z;
+        q.of2x = q.ofx; q.of2y = q.ofy; q.of2z = q.ofz;
     }
     return q;
 }
-// The ray as the reference's own (k - o) / d wants it (face_t<true>).
-DEV SlabRay exact_slab_ray(const Ray& r) {
-    SlabRay q;
-    q.of = to_v3(r.o);
-    q.invd = to_v3(r.d);
-    return q;
-}
 
-// AABB::hit, bhv.rs:29-42 (quirk Q5).  Evaluating the three slabs and testing once equals the reference's
+// AABB::hit, bhv.rs:29-42 (quirk Q5), for f64 entries.  Evaluating the three slabs and testing once equals the reference's
 // per-axis early exit because the interval only shrinks.
-DEV bool slab_hit(const DNode<real>& n, const SlabRay& r, real tmin, real tmax) {
-    real t0 = slab_t(n.v[0], r.of.x, r.invd.x), t1 = slab_t(n.v[3], r.of.x, r.invd.x);
-    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    t0 = slab_t(n.v[1], r.of.y, r.invd.y); t1 = slab_t(n.v[4], r.of.y, r.invd.y);
-    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    t0 = slab_t(n.v[2], r.of.z, r.invd.z); t1 = slab_t(n.v[5], r.of.z, r.invd.z);
-    tmin = max_r(min_r(t0, t1), tmin); tmax = min_r(max_r(t0, t1), tmax);
-    // fast build: 2-ulp slack on the far bound keeps the f32 cull conservative against the f64 hit distance
-#ifndef MLRT_NO_ROBUST
-    if (kFast) return !(tmax * (real)1.0000003 <= tmin);
-#endif
-    if (kProduct64) return !(tmax * (real)kCullSlack64 <= tmin);
+DEV bool slab_hit(const DNode<creal>& n, const SlabRay& r, double tmin, double tmax) {
+    double t0 = slab_t(n.v[0], r.ofx, r.ix), t1 = slab_t(n.v[3], r.ofx, r.ix);
+    tmin = fmax(fmin(t0, t1), tmin); tmax = fmin(fmax(t0, t1), tmax);
+    t0 = slab_t(n.v[1], r.ofy, r.iy); t1 = slab_t(n.v[4], r.ofy, r.iy);
+    tmin = fmax(fmin(t0, t1), tmin); tmax = fmin(fmax(t0, t1), tmax);
+    t0 = slab_t(n.v[2], r.ofz, r.iz); t1 = slab_t(n.v[5], r.ofz, r.iz);
+    tmin = fmax(fmin(t0, t1), tmin); tmax = fmin(fmax(t0, t1), tmax);
+    if (!kStrict) return !(tmax * kCullSlack64 <= tmin);
     return !(tmax <= tmin);
 }
-// The same decision for the fast build with two instructions less per step: the far bound min(far, closest) * slack is
+// The same decision over f32 entries with two instructions less per step: the far bound min(far, closest) * slack is
 // min(far * slack, closest * slack) (rounding is monotone), and closest * slack changes only when a hit is accepted, so
 // the caller passes it in: no min with - and no canonicalisation of - a value the compiler cannot see the origin of.
-DEV bool slab_hit_fast(const DNode<float>& n, const SlabRay& r, float closest_slack) {
-    float t0 = slab_t(n.v[0], r.of.x, r.invd.x), t1 = slab_t(n.v[3], r.of.x, r.invd.x);
+DEV bool slab_hit_fast(const DNode<creal>& n, const SlabRay& r, float closest_slack) {
+    float t0 = slab_t(n.v[0], r.ofx, r.ix), t1 = slab_t(n.v[3], kRigorousCull ? r.of2x : r.ofx, r.ix);
     float tnear = fmaxf(fminf(t0, t1), 0.001f), tfar = fmaxf(t0, t1);
-    t0 = slab_t(n.v[1], r.of.y, r.invd.y); t1 = slab_t(n.v[4], r.of.y, r.invd.y);
+    t0 = slab_t(n.v[1], r.ofy, r.iy); t1 = slab_t(n.v[4], kRigorousCull ? r.of2y : r.ofy, r.iy);
     tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
-    t0 = slab_t(n.v[2], r.of.z, r.invd.z); t1 = slab_t(n.v[5], r.of.z, r.invd.z);
+    t0 = slab_t(n.v[2], r.ofz, r.iz); t1 = slab_t(n.v[5], kRigorousCull ? r.of2z : r.ofz, r.iz);
     tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
     // (closest_slack and tnear are positive and not NaN - tnear >= 0.001 by the fmaxf above - so the second comparison is done
     // on the bit patterns: written on floats the compiler folds the two back into one min, canonicalisation included)
-    return !(tfar * 1.0000003f <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
+    return !(tfar * kSlack32 <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
 }
 // closest-so-far as the slab tests of the current build want it
-DEV real slab_far_bound(double closest) { return kFast ? (real)((float)closest * 1.0000003f) : (real)closest; }  // (f64 product: slab_hit applies the slack)
-template <typename R>
-DEV bool slab_hit_any(const DNode<R>& n, const SlabRay& r, R far_bound) {
-    if constexpr (sizeof(R) == 4) return slab_hit_fast(n, r, far_bound);
-    else return slab_hit(n, r, (R)0.001, far_bound);
+DEV creal slab_far_bound(double closest) { return kCull32 ? (creal)((float)closest * kSlack32) : (creal)closest; }  // (f64 entries: slab_hit applies the slack)
+DEV bool slab_hit_any(const DNode<creal>& n, const SlabRay& r, creal far_bound) {
+    if (kCull32) return slab_hit_fast(n, r, (float)far_bound);
+    return slab_hit(n, r, 0.001, (double)far_bound);
 }
 
-// Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in BOTH builds: with the radius-1000 ground
+// Sphere::hit, shapes.rs:58-82.  The quadratic is evaluated in f64 in EVERY build: with the radius-1000 ground
 // sphere of `random` (worlds.rs:83) |oc|^2 - r^2 cancels catastrophically in f32.  MI355X runs f64 FMA at half
 // the f32 rate, so this is affordable; the fast build avoids the f64 divide and square-root sequences.
 // The quadratic of Sphere::hit: discriminant >= 0, and its two roots evaluated exactly as sphere_hit's callers always did
 // (near root first; the far root by the same expression with the sign of the square root flipped).
-DEV bool sphere_roots(const DNode<real>& n, const Ray& r, double& near_root, double& far_root) {
+DEV bool sphere_roots(const SphereP& s, const Ray& r, double& near_root, double& far_root) {
 #pragma clang fp contract(off)
-    const double ocx = r.o.x - (double)n.v[0], ocy = r.o.y - (double)n.v[1], ocz = r.o.z - (double)n.v[2];
-    const double radius = (double)n.v[3];
+    const double ocx = r.o.x - s.cx, ocy = r.o.y - s.cy, ocz = r.o.z - s.cz;
+    const double radius = s.r;
     const double half_b = dfma(ocz, r.d.z, dfma(ocy, r.d.y, ocx * r.d.x));           // oc.dot(dir)
     const double c = dfma(ocz, ocz, dfma(ocy, ocy, ocx * ocx)) - radius * radius;   // oc.length_squared() - r*r
     const double discriminant = dfma(half_b, half_b, -(r.a * c));                   // half_b*half_b - a*c
@@ -455,9 +510,9 @@ DEV bool sphere_roots(const DNode<real>& n, const Ray& r, double& near_root, dou
     }
     return true;
 }
-DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+DEV bool sphere_hit(const SphereP& s, const Ray& r, double tmin, double tmax, double& t_out) {
     double root, far_root;
-    if (!sphere_roots(n, r, root, far_root)) return false;
+    if (!sphere_roots(s, r, root, far_root)) return false;
     if (root < tmin || tmax < root) {
         root = far_root;
         if (root < tmin || tmax < root) return false;
@@ -469,19 +524,12 @@ DEV bool sphere_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax
 // Block::hit = HittableList of six AARects (shapes.rs:172-192, hittable.rs:53-69): the nearest face hit inside
 // [tmin, tmax].  The faces a line can hit inside their rectangles are the slab entry and exit faces, so the six
 // rect tests collapse into one slab evaluation with the same t = (k - o)/d per face.
-template <bool EXACT>
-DEV bool box_hit(const DNode<real>& n, const SlabRay& r, double tmin, double tmax, double& t_out, int& axis_out) {
-    real lo[3], hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const real oa = comp(r.of, a), ia = comp(r.invd, a);
-        const real t0 = face_t<EXACT>(n.v[a], oa, ia), t1 = face_t<EXACT>(n.v[3 + a], oa, ia);
-        lo[a] = min_r(t0, t1); hi[a] = max_r(t0, t1);
-    }
-    real te = lo[0]; int ae = 0;
+template <typename T>
+DEV bool box_faces(const T (&lo)[3], const T (&hi)[3], double tmin, double tmax, double& t_out, int& axis_out) {
+    T te = lo[0]; int ae = 0;
     if (lo[1] > te) { te = lo[1]; ae = 1; }
     if (lo[2] > te) { te = lo[2]; ae = 2; }
-    real tx = hi[0]; int ax = 0;
+    T tx = hi[0]; int ax = 0;
     if (hi[1] < tx) { tx = hi[1]; ax = 1; }
     if (hi[2] < tx) { tx = hi[2]; ax = 2; }
     if (te > tx) return false;
@@ -489,38 +537,65 @@ DEV bool box_hit(const DNode<real>& n, const SlabRay& r, double tmin, double tma
     if ((double)tx >= tmin && (double)tx <= tmax) { t_out = (double)tx; axis_out = ax; return true; }
     return false;
 }
+// f64 builds: the reference's own t = (k - origin) / direction per face (aarects.rs:46) - the distance of an accepted hit must
+// not carry a culling form's rounding
+DEV bool box_hit_exact(const double (&b)[6], P3 o, P3 d, double tmin, double tmax, double& t_out, int& axis_out) {
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double oa = compp(o, a), da = compp(d, a);
+        const double t0 = (b[a] - oa) / da, t1 = (b[3 + a] - oa) / da;
+        lo[a] = fmin(t0, t1); hi[a] = fmax(t0, t1);
+    }
+    return box_faces(lo, hi, tmin, tmax, t_out, axis_out);
+}
+// fast build: the culling form's t (one fma per face) from the entry's inline f32 bounds
+DEV bool box_hit_fast(const DNode<creal>& n, const SlabRay& r, double tmin, double tmax, double& t_out, int& axis_out) {
+    float lo[3], hi[3];
+    const float of[3] = {(float)r.ofx, (float)r.ofy, (float)r.ofz}, iv[3] = {(float)r.ix, (float)r.iy, (float)r.iz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float t0 = __builtin_fmaf((float)n.v[a], iv[a], of[a]), t1 = __builtin_fmaf((float)n.v[3 + a], iv[a], of[a]);
+        lo[a] = fminf(t0, t1); hi[a] = fmaxf(t0, t1);
+    }
+    return box_faces(lo, hi, tmin, tmax, t_out, axis_out);
+}
 
 // AARect::hit, aarects.rs:45-64
-DEV bool rect_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out) {
+DEV bool rect_hit(const Scene& S, int idx, const DNode<creal>& n, const Ray& r, double tmin, double tmax, double& t_out) {
     const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
     if (kFast) {
-        const real t = ((real)n.v[4] - (real)compp(r.o, ap)) * fast_rcp((real)compp(r.d, ap));
+        const float t = ((float)n.v[4] - (float)compp(r.o, ap)) * fast_rcp((float)compp(r.d, ap));
         if ((double)t < tmin || (double)t > tmax) return false;
-        const real a0_v = (real)compp(r.o, a0) + t * (real)compp(r.d, a0);
-        const real a1_v = (real)compp(r.o, a1) + t * (real)compp(r.d, a1);
-        if (a0_v < n.v[0] || a0_v > n.v[1] || a1_v < n.v[2] || a1_v > n.v[3]) return false;
+        const float a0_v = (float)compp(r.o, a0) + t * (float)compp(r.d, a0);
+        const float a1_v = (float)compp(r.o, a1) + t * (float)compp(r.d, a1);
+        if (a0_v < (float)n.v[0] || a0_v > (float)n.v[1] || a1_v < (float)n.v[2] || a1_v > (float)n.v[3]) return false;
         t_out = (double)t;
         return true;
     }
-    const double t = ((double)n.v[4] - compp(r.o, ap)) / compp(r.d, ap);
+    double v[5];
+    prim_params<5>(S, idx, n, v);
+    const double t = (v[4] - compp(r.o, ap)) / compp(r.d, ap);
     if (t < tmin || t > tmax) return false;
     const double a0_v = compp(r.o, a0) + t * compp(r.d, a0);
     const double a1_v = compp(r.o, a1) + t * compp(r.d, a1);
-    if (a0_v < (double)n.v[0] || a0_v > (double)n.v[1] || a1_v < (double)n.v[2] || a1_v > (double)n.v[3]) return false;
+    if (a0_v < v[0] || a0_v > v[1] || a1_v < v[2] || a1_v > v[3]) return false;
     t_out = t;
     return true;
 }
 
+// The primitive whose entry is `idx` (n = that entry) against the f64 ray.
 template <uint32_t FEAT>
-DEV bool prim_hit(const DNode<real>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
+DEV bool prim_hit(const Scene& S, int idx, const DNode<creal>& n, const Ray& r, double tmin, double tmax, double& t_out, int& aux) {
     const int kind = n.tag & TAG_KIND_MASK;
-    if (kind == TAG_SPHERE) return sphere_hit(n, r, tmin, tmax, t_out);
+    if (kind == TAG_SPHERE) return sphere_hit(sphere_params(S, idx, n), r, tmin, tmax, t_out);
     if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
-        // fast build: the culling form's t (one fma per face); f64 builds: the reference's division
-        if (kFast) return box_hit<false>(n, slab_ray(r), tmin, tmax, t_out, aux);
-        return box_hit<true>(n, exact_slab_ray(r), tmin, tmax, t_out, aux);
+        if (kFast) return box_hit_fast(n, slab_ray(r), tmin, tmax, t_out, aux);
+        double b[6];
+        prim_params<6>(S, idx, n, b);
+        return box_hit_exact(b, r.o, r.d, tmin, tmax, t_out, aux);
     }
-    if ((FEAT & FEAT_RECT) && kind == TAG_RECT) return rect_hit(n, r, tmin, tmax, t_out);
+    if ((FEAT & FEAT_RECT) && kind == TAG_RECT) return rect_hit(S, idx, n, r, tmin, tmax, t_out);
     return false;  // TAG_EMPTY: shapes.rs:8-23
 }
 
@@ -538,27 +613,29 @@ struct Cursor {
 // Entries that are not plain box tests: primitives with f64 arithmetic, media, transform brackets.  Executed in
 // batches (see the kernel loop), so the long code below is issued for many lanes at once.
 template <uint32_t FEAT>
-DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
+DEV void special_entry(const Scene& S, const DNode<creal>& n, Cursor& c, P3 o, P3 d, Rng& g, RngKey key) {
     const double t_min = 0.001;  // raytrace.rs:90
     const int kind = n.tag & TAG_KIND_MASK;
     if ((FEAT & FEAT_XFORM) && (kind == TAG_XFORM || kind == TAG_XFORM_END)) {
         c.xf = kind == TAG_XFORM ? c.node : -1;
         c.sr = slab_ray(local_ray<FEAT>(S, c.xf, o, d));
-        c.node += 1;
+        c.node += slots_of(n.tag);
         return;
     }
     const Ray r = local_ray<FEAT>(S, c.xf, o, d);
     if ((FEAT & FEAT_MEDIUM) && kind == TAG_MEDIUM) {
         // ConstantMedium::hit, volumes.rs:26-65 (quirk Q9: the draw happens only when the clamped interval is non-empty)
-        const DNode<real> boundary = S.nodes[c.node + 1];
+        const int b_idx = c.node + slots_of(n.tag);
+        const DNode<creal> boundary = S.nodes[b_idx];
         double t1, t2; int aux = 0;
         bool through;
         if ((boundary.tag & TAG_KIND_MASK) == TAG_SPHERE) {
             // boundary.hit(-inf, inf) is the near root and boundary.hit(t1 + 0.001, inf) the far one when it is not below
             // t1 + 0.001 (shapes.rs:66-73): ONE evaluation of the quadratic instead of two identical ones
-            through = sphere_roots(boundary, r, t1, t2) && !(t2 < t1 + 0.001);
+            through = sphere_roots(sphere_params(S, b_idx, boundary), r, t1, t2) && !(t2 < t1 + 0.001);
         } else {
-            through = prim_hit<FEAT>(boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) && prim_hit<FEAT>(boundary, r, t1 + 0.001, (double)INFINITY, t2, aux);
+            through = prim_hit<FEAT>(S, b_idx, boundary, r, -(double)INFINITY, (double)INFINITY, t1, aux) &&
+                      prim_hit<FEAT>(S, b_idx, boundary, r, t1 + 0.001, (double)INFINITY, t2, aux);
         }
         if (through) {
             t1 = fmax(t1, t_min);
@@ -579,19 +656,21 @@ DEV void special_entry(const Scene& S, const DNode<real>& n, Cursor& c, P3 o, P3
                 }
                 const double distance_inside = (t2 - t1) * ray_scale;
                 const double xi = u01d(rng_next(g, key));
-                const double hit_distance = (double)n.v[0] * (kFast ? (double)(__builtin_amdgcn_logf((float)xi) * 0.693147180559945f) : log(xi));  // (v_log_f32 is log2; xi = 0 gives -inf: no hit, as with ln)
+                double density[1];
+                prim_params<1>(S, c.node, n, density);  // neg_inv_density
+                const double hit_distance = density[0] * (kFast ? (double)(__builtin_amdgcn_logf((float)xi) * 0.693147180559945f) : log(xi));  // (v_log_f32 is log2; xi = 0 gives -inf: no hit, as with ln)
                 if (!(hit_distance > distance_inside)) {
                     c.closest = kFast ? dfma(hit_distance, inv_ray_scale, t1) : t1 + hit_distance / ray_scale;
                     c.hit_node = c.node; c.hit_aux = 0; c.hit_xf = c.xf;
                 }
             }
         }
-        c.node += 2;
+        c.node = b_idx + slots_of(boundary.tag);
         return;
     }
     double t; int aux = 0;
-    if (prim_hit<FEAT>(n, r, t_min, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
-    c.node += 1;
+    if (prim_hit<FEAT>(S, c.node, n, r, t_min, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+    c.node += slots_of(n.tag);
 }
 
 // ---------------------------------------------------------------------------------------------- textures
@@ -732,7 +811,7 @@ struct HitAttr {
 };
 template <uint32_t FEAT>
 DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
-    const DNode<real> n = S.nodes[c.hit_node];
+    const DNode<creal> n = S.nodes[c.hit_node];
     const int kind = n.tag & TAG_KIND_MASK;
     P3 p;
     V3 normal;
@@ -745,23 +824,26 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
         normal = mk((real)1, (real)0, (real)0);
     } else {
         P3 oo = o, od = d;
-        DNode<real> xf;
-        xf.tag = 0;
-        if ((FEAT & FEAT_XFORM) && c.hit_xf >= 0) { xf = S.nodes[c.hit_xf]; to_object(xf, oo, od); }
+        XfP xf;
+        xf.tag = 0; xf.sin_t = 0.0; xf.cos_t = 1.0; xf.ox = xf.oy = xf.oz = 0.0;
+        if ((FEAT & FEAT_XFORM) && c.hit_xf >= 0) { xf = xform_params(S, c.hit_xf); to_object(xf, oo, od); }
         const P3 po = ray_at(oo, od, c.closest);
         const V3 odf = to_v3(od);
         V3 outward = mk(0, 0, 1);
         if (kind == TAG_SPHERE) {
-            if (kFast) outward = to_v3(po - mkp((double)n.v[0], (double)n.v[1], (double)n.v[2])) * fast_rcp(n.v[3]);
-            else outward = mk((real)((po.x - (double)n.v[0]) / (double)n.v[3]), (real)((po.y - (double)n.v[1]) / (double)n.v[3]), (real)((po.z - (double)n.v[2]) / (double)n.v[3]));
+            const SphereP sp = sphere_params(S, c.hit_node, n);
+            if (kFast) outward = to_v3(po - mkp(sp.cx, sp.cy, sp.cz)) * fast_rcp((real)sp.r);
+            else outward = mk((real)((po.x - sp.cx) / sp.r), (real)((po.y - sp.cy) / sp.r), (real)((po.z - sp.cz) / sp.r));
             if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) sphere_uv(outward, u, v);
         } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
             outward = axis_vec(c.hit_aux, (real)1);
         } else if (FEAT & FEAT_RECT) {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);
-            u = div_r((real)compp(po, a0) - n.v[0], n.v[1] - n.v[0]);
-            v = div_r((real)compp(po, a1) - n.v[2], n.v[3] - n.v[2]);
+            double rv[5];
+            prim_params<5>(S, c.hit_node, n, rv);
+            u = div_r((real)compp(po, a0) - (real)rv[0], (real)rv[1] - (real)rv[0]);
+            v = div_r((real)compp(po, a1) - (real)rv[2], (real)rv[3] - (real)rv[2]);
         }
         front_face = dot(outward, odf) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
         normal = front_face ? outward : -outward;
@@ -774,7 +856,7 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
                 normal = front_face ? nw : -nw;
             }
             if (xf_translates(xf)) {  // Translate::hit, transforms.rs:36-39 (moved_r.dir == r.dir)
-                p = p + mkp((double)xf.v[2], (double)xf.v[3], (double)xf.v[4]);
+                p = p + mkp(xf.ox, xf.oy, xf.oz);
                 front_face = dot(normal, dw) < (real)0;
                 normal = front_face ? normal : -normal;
             }
@@ -946,14 +1028,15 @@ DEV unsigned long long to_fixed(float c) {
 #ifndef MLRT_T_SHADE_LEAN
 #define MLRT_T_SHADE_LEAN 40
 #endif
-enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };  // WAIT: no sample to be had until a bank of the ring drains
+enum { PH_TRAV = 0, PH_SPECIAL = 1, PH_SHADE = 2, PH_IDLE = 3, PH_WAIT = 4 };
+static_assert(PH_TRAV == 0 && PH_SPECIAL == 1, "the traversal step computes the phase from the tag's sign bit");  // WAIT: no sample to be had until a bank of the ring drains
 
 // The traversal is latency bound (rocprof: waves wait on LDS 40 % of their cycles at 4 waves per SIMD), so the entry for
 // a lane's NEXT step is fetched in ONE round trip (both 16-byte halves, all lanes, clamped index) right after the cursor
 // moved, and the batch bookkeeping runs while it is in flight.  pin_entry marks where it must have arrived, which also
 // stops the compiler from sinking the loads behind the tag test (two dependent round trips per step).
-DEV DNode<real> fetch_entry(const Scene& S, int node, int n_nodes) { return S.nodes[node]; }  // node <= n_nodes: the sentinel
-DEV void pin_entry(const DNode<real>& n) {
+DEV DNode<creal> fetch_entry(const Scene& S, int node, int n_nodes) { return S.nodes[node]; }  // node <= n_nodes: the sentinel
+DEV void pin_entry(const DNode<creal>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
 
@@ -976,7 +1059,7 @@ constexpr int kCoarseMax = 256;
 __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* records) {
     __shared__ uint16_t coarse[kCoarseMax];
     const int lane = threadIdx.x;
-    const DNode<real>* nodes = reinterpret_cast<const DNode<real>*>(P.blob + P.off_nodes);
+    const DNode<creal>* nodes = reinterpret_cast<const DNode<creal>*>(P.blob + P.off_nodes);
     const int spans_per_row = (P.tiles_per_row + 63) >> 6;
     const int row_k = (int)blockIdx.x / spans_per_row;
     const int gx0 = ((int)blockIdx.x - row_k * spans_per_row) << 6;
@@ -1014,19 +1097,26 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
         py.left = plane(d00, d01); py.right = plane(d10, d11); py.bottom = plane(d00, d10); py.top = plane(d01, d11);
         return py;
     };
-    auto touches = [&](const Pyramid& py, const DNode<real>& q) {
-        if ((q.tag & TAG_KIND_MASK) != TAG_SPHERE) return false;
-        const V3 cc = mk(q.v[0], q.v[1], q.v[2]) - of;
+    // (the sphere entries are listed in the blob: payload slots make the entry array unsafe to scan blindly)
+    const uint16_t* sphere_index = reinterpret_cast<const uint16_t*>(P.blob + P.off_sphere_index);
+    auto touches = [&](const Pyramid& py, int e) {
+        const DNode<creal> q = nodes[e];
+        double cx, cy, cz, rad;
+        if (kPayloadAll) { const double* pl = reinterpret_cast<const double*>(&nodes[e + 1]); cx = pl[0]; cy = pl[1]; cz = pl[2]; rad = pl[3]; }
+        else { cx = (double)q.v[0]; cy = (double)q.v[1]; cz = (double)q.v[2]; rad = (double)q.v[3]; }
+        const V3 cc = mk((real)cx, (real)cy, (real)cz) - of;
+        const real radius = abs_r((real)rad);
         const real far = abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z);  // >= |cc|
-        const real reach = abs_r(q.v[3]) * (real)1.00001 + (real)1e-3 + (real)1e-5 * far + lens * max_r((real)1, (far + abs_r(q.v[3])) * inv_focus);
+        const real reach = radius * (real)1.00001 + (real)1e-3 + (real)1e-5 * far + lens * max_r((real)1, (far + radius) * inv_focus);
         return dot(py.left, cc) >= -reach && dot(py.right, cc) >= -reach && dot(py.bottom, cc) >= -reach && dot(py.top, cc) >= -reach;
     };
     // level 1: the span's survivors, in entry order
     const Pyramid span = pyramid(gx0 * P.pix_per_tile, min(P.width, (gx0 + 64) * P.pix_per_tile));
     int n_coarse = 0;  // wave-uniform
-    for (int e0 = 0; e0 < P.n_nodes; e0 += 64) {
-        const int e = e0 + lane;
-        const bool in = e < P.n_nodes && touches(span, nodes[e < P.n_nodes ? e : 0]);
+    for (int k0 = 0; k0 < P.n_sphere_index; k0 += 64) {
+        const int k = k0 + lane;
+        const int e = (int)sphere_index[k < P.n_sphere_index ? k : 0];
+        const bool in = k < P.n_sphere_index && touches(span, e);
         const unsigned long long mask = __ballot(in);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
         if (in && n_coarse + rank < kCoarseMax) coarse[n_coarse + rank] = (uint16_t)e;
@@ -1034,7 +1124,7 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     }
     __syncthreads();
     const bool flat = n_coarse > kCoarseMax;
-    const int n_candidates = flat ? P.n_nodes : n_coarse;
+    const int n_candidates = flat ? P.n_sphere_index : n_coarse;
     // level 2: the lane's own pixel group
     if (gx >= P.tiles_per_row) return;
     const int x0 = gx * P.pix_per_tile;
@@ -1044,8 +1134,8 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     for (int k = 0; k < kCandRecord; k++) list[k] = 0;
     int count = 0;
     for (int k = 0; k < n_candidates; k++) {
-        const int e = flat ? k : (int)coarse[k];
-        if (touches(own, nodes[e])) {
+        const int e = flat ? (int)sphere_index[k] : (int)coarse[k];
+        if (touches(own, e)) {
 #pragma unroll
             for (int m = 0; m < kCand; m++) if (m == count) list[1 + m] = (uint16_t)e;
             count++;
@@ -1102,7 +1192,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     }
     __syncthreads();
     Scene S;
-    S.nodes = reinterpret_cast<const DNode<real>*>(base + P.off_nodes);
+    S.nodes = reinterpret_cast<const DNode<creal>*>(base + P.off_nodes);
     S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
     S.textures = reinterpret_cast<const DTexture<real>*>(base + P.off_textures);
     S.perlin_vec = reinterpret_cast<const real*>(base + P.off_perlin_vec);
@@ -1157,7 +1247,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     Rng g = {0u, 0u, 0u, 0u};
     Cursor c;
     c.node = 0; c.xf = -1; c.closest = 0.0; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
-    c.sr.of = mk(0, 0, 0); c.sr.invd = mk(1, 1, 1);
+    c.sr.ofx = c.sr.ofy = c.sr.ofz = (creal)0; c.sr.ix = c.sr.iy = c.sr.iz = (creal)1; c.sr.of2x = c.sr.of2y = c.sr.of2z = (creal)0;
 
     // Tiles whose last sample has finished: the WAVE looks at the banks' counts once per shading batch (one LDS read for
     // all banks; LDS operations of a wave execute in order, so every add of a tile is visible when its count reads zero)
@@ -1179,7 +1269,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         return true;
     };
 
-    DNode<real> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
+    DNode<creal> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
     for (;;) {
         // (A) MLRT_STEPS traversal steps between two looks at the batches: the ballots and threshold tests of (B) and (C)
         // are a fifth of an iteration's instructions, and a lane that parks waits at most three steps longer for
@@ -1189,7 +1279,7 @@ void mlrt_render_kernel(const KParams<real> P) {
 #define MLRT_STEPS 4
 #endif
         if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
-        real far_bound = slab_far_bound(c.closest);  // (hits are accepted in the batches, and by box entries in the full variant's step)
+        creal far_bound = slab_far_bound(c.closest);  // (hits are accepted in the batches, and by box entries in the full variant's step)
 #pragma unroll
         for (int sub = 0; sub < MLRT_STEPS; sub++) {
         pin_entry(n);
@@ -1201,31 +1291,39 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (FEAT == 0) {
             if (phase == PH_TRAV) {
                 // (inner entries and the sentinel carry no flag bits: the tag is compared whole)
-                if (n.tag == TAG_INNER) c.node = slab_hit_any<real>(n, c.sr, far_bound) ? c.node + 1 : n.link;
+                if (n.tag == TAG_INNER) c.node = slab_hit_any(n, c.sr, far_bound) ? c.node + 1 : n.link;
                 else phase = n.tag == TAG_END ? PH_SHADE : PH_SPECIAL;
             }
         } else {
             const int kind = n.tag & TAG_KIND_MASK;
             const bool trav = phase == PH_TRAV;
             const bool inner = trav && kind == TAG_INNER;
-            const bool inside = slab_hit_any<real>(n, c.sr, far_bound);
+            const bool inside = slab_hit_any(n, c.sr, far_bound);
             c.node = inner ? (inside ? c.node + 1 : n.link) : c.node;
             bool handled = inner;
             if ((FEAT & FEAT_BOX) && !MLRT_BOX_SPECIAL && !kProduct64) {
-                // (c.sr is the culling form of the ray in the fast build and the reference's own (o, d) in the strict build)
+                // Block entries resolved in the step: the fast build from the same slab evaluation (culling form, f32), the strict
+                // build with the reference's divisions (its c.sr is the ray's own origin and direction)
                 const bool box = trav && kind == TAG_BOX;
                 if (box) {
                     double t; int aux = 0;
-                    if (box_hit<kStrict>(n, c.sr, 0.001, c.closest, t, aux)) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; far_bound = slab_far_bound(t); }
+                    bool hit_box;
+                    if (kFast) {
+                        hit_box = box_hit_fast(n, c.sr, 0.001, c.closest, t, aux);
+                    } else {
+                        const double b[6] = {(double)n.v[0], (double)n.v[1], (double)n.v[2], (double)n.v[3], (double)n.v[4], (double)n.v[5]};
+                        hit_box = box_hit_exact(b, mkp((double)c.sr.ofx, (double)c.sr.ofy, (double)c.sr.ofz), mkp((double)c.sr.ix, (double)c.sr.iy, (double)c.sr.iz), 0.001, c.closest, t, aux);
+                    }
+                    if (hit_box) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; far_bound = slab_far_bound(t); }
                     c.node += 1;
                 }
                 handled = handled || box;
             }
             if ((FEAT & FEAT_BOX) && kProduct64) {
-                // product f64 build: a Block the ray's culling test misses is passed in the step; one it may hit parks the lane
-                // for the special batch, where the face distances are the reference's divisions (box_hit<true>)
+                // product f64 builds: a Block whose (outward) bounds the culling test misses is passed in the step; one the ray may
+                // hit parks the lane for the special batch, where the face distances are the reference's divisions
                 const bool box_missed = trav && kind == TAG_BOX && !inside;
-                c.node = box_missed ? c.node + 1 : c.node;
+                c.node = box_missed ? c.node + slots_of(n.tag) : c.node;
                 handled = handled || box_missed;
             }
             phase = (trav && !handled) ? (kind == TAG_END ? PH_SHADE : PH_SPECIAL) : phase;

@@ -24,22 +24,23 @@ def equality(name, W, aspect, spp, n_rows=6, aperture=0.0, focus=None):
     params = pkg.make_params(w, W, H, spp)
     rows = np.unique(np.linspace(0, H - 1, n_rows).astype(np.int32))
     out = {}
-    for prec, tag in ((pkg.PRECISION_FP64, "f64"), (pkg.PRECISION_FP64_STRICT, "f64s")):
-        r = pkg.Renderer(w, cam, params, precision=prec)
+    for prec, tag in ((pkg.PRECISION_FP64, "f64"), (pkg.PRECISION_FP64, "f64c"), (pkg.PRECISION_FP64_STRICT, "f64s")):
+        r = pkg.Renderer(w, cam, params, precision=prec, opts=pkg.options(cull_f64=1) if tag == "f64c" else None)
         out[tag] = sums(r, rows, W)
         info = r.info()
         r.close()
         print("  %s %s: %d rows kernel %.1f ms %s" % (name, tag, len(rows), out[tag][2], info), flush=True)
-    same_rgb = np.array_equal(out["f64"][0], out["f64s"][0])
-    n_diff = int(np.sum(out["f64"][1] != out["f64s"][1]))
-    print("%s %dx%d spp %d: rgb equal %s, differing f64 sums %d of %d" % (name, W, H, spp, same_rgb, n_diff, out["f64"][1].size), flush=True)
+    for tag in ("f64", "f64c"):
+        same_rgb = np.array_equal(out[tag][0], out["f64s"][0])
+        n_diff = int(np.sum(out[tag][1] != out["f64s"][1]))
+        print("%s %dx%d spp %d: %s vs strict: rgb equal %s, differing f64 sums %d of %d" % (name, W, H, spp, tag, same_rgb, n_diff, out[tag][1].size), flush=True)
     w.close()
 
 
-def timing(name, W, aspect, spp, prec, reps=3):
+def timing(name, W, aspect, spp, prec, reps=3, **opts):
     w = pkg.World(name, 42)
     H = pkg.image_height(W, aspect)
-    r = pkg.Renderer(w, pkg.default_camera(w, aspect), pkg.make_params(w, W, H, spp), precision=prec)
+    r = pkg.Renderer(w, pkg.default_camera(w, aspect), pkg.make_params(w, W, H, spp), precision=prec, opts=pkg.options(**opts) if opts else None)
     d_rgb = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
     ms = []
     for _ in range(reps + 1):
@@ -62,6 +63,8 @@ if __name__ == "__main__":
         equality("earth", 200, 1.5, 32)
     if "time" in which:
         timing("random", 1200, 1.5, 500, pkg.PRECISION_FP64)
+        timing("random", 1200, 1.5, 500, pkg.PRECISION_FP64, cull_f64=1)
         timing("random", 1200, 1.5, 500, pkg.PRECISION_FP32)
         timing("final_scene", 800, 1.0, 200, pkg.PRECISION_FP64)
+        timing("final_scene", 800, 1.0, 200, pkg.PRECISION_FP64, cull_f64=1)
         timing("final_scene", 800, 1.0, 200, pkg.PRECISION_FP32)

@@ -13,7 +13,7 @@ def run(name, W, aspect, spp, reps=3, aperture=0.0, focus=None):
     H = pkg.image_height(W, aspect)
     cam = pkg.default_camera(w, aspect, aperture, focus)
     params = pkg.make_params(w, W, H, spp)
-    r = pkg.Renderer(w, cam, params)
+    r = pkg.Renderer(w, cam, params, precision=int(os.environ.get('MLRT_PREC', '0')))
     d_rgb = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
     ms = []
     for _ in range(reps + 1):

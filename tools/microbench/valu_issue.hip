@@ -1,0 +1,133 @@
+// tools/microbench/valu_issue.hip - what ONE SIMD of gfx950 sustains per vector instruction class, measured.
+//
+// The render kernels are bound by vector-instruction issue, so bench.py's roofline prices the kernel's VALU
+// work against the chip's VALU issue capacity.  This microbenchmark supplies the prices: for each instruction class, a
+// saturating stream of independent instructions from W waves per SIMD, timed with the shader clock (s_memtime), gives
+// cycles per wave-instruction per SIMD.  Run under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES`
+// it also calibrates what the SQ counters report per instruction of each class (profiles/r02_valu_issue_*.txt).
+//
+//   hipcc --offload-arch=gfx950 -O2 tools/microbench/valu_issue.hip -o gpurun_out/valu_issue && gpurun_out/valu_issue
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+constexpr int kUnroll = 16;     // independent instructions per loop body (different destination registers)
+constexpr int kIters = 8192;
+
+// One kernel per instruction class: OP is the asm template with %0 = in/out register of chain k, %1, %2 = constants.
+#define DEFINE_KERNEL_F32(NAME, ASM)                                                                         \
+    __global__ __launch_bounds__(256) void NAME(float* out, unsigned long long* cycles, float b, float c) { \
+        float a[kUnroll];                                                                                    \
+        for (int k = 0; k < kUnroll; k++) a[k] = (float)(threadIdx.x + k) * 1e-3f + 1.0f;                    \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                          \
+        for (int it = 0; it < kIters; it++) {                                                                \
+            _Pragma("unroll") for (int k = 0; k < kUnroll; k++) asm volatile(ASM : "+v"(a[k]) : "v"(b), "v"(c) : "vcc"); \
+        }                                                                                                    \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                          \
+        float s = 0; for (int k = 0; k < kUnroll; k++) s += a[k];                                            \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                      \
+        if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;        \
+    }
+#define DEFINE_KERNEL_F64(NAME, ASM)                                                                          \
+    __global__ __launch_bounds__(256) void NAME(double* out, unsigned long long* cycles, double b, double c) { \
+        double a[kUnroll];                                                                                    \
+        for (int k = 0; k < kUnroll; k++) a[k] = (double)(threadIdx.x + k) * 1e-3 + 1.0;                      \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                           \
+        for (int it = 0; it < kIters; it++) {                                                                 \
+            _Pragma("unroll") for (int k = 0; k < kUnroll; k++) asm volatile(ASM : "+v"(a[k]) : "v"(b), "v"(c) : "vcc"); \
+        }                                                                                                     \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                           \
+        double s = 0; for (int k = 0; k < kUnroll; k++) s += a[k];                                            \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                       \
+        if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;         \
+    }
+
+DEFINE_KERNEL_F32(k_fma_f32, "v_fma_f32 %0, %0, %1, %2")
+DEFINE_KERNEL_F32(k_add_f32, "v_add_f32 %0, %0, %1")
+DEFINE_KERNEL_F32(k_max_f32, "v_max_f32 %0, %0, %1")
+DEFINE_KERNEL_F32(k_rcp_f32, "v_rcp_f32 %0, %0")
+DEFINE_KERNEL_F32(k_sqrt_f32, "v_sqrt_f32 %0, %0")
+DEFINE_KERNEL_F32(k_sin_f32, "v_sin_f32 %0, %0")
+DEFINE_KERNEL_F32(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
+DEFINE_KERNEL_F32(k_xor_b32, "v_xor_b32 %0, %0, %1")
+DEFINE_KERNEL_F32(k_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
+DEFINE_KERNEL_F64(k_fma_f64, "v_fma_f64 %0, %0, %1, %2")
+DEFINE_KERNEL_F64(k_add_f64, "v_add_f64 %0, %0, %1")
+DEFINE_KERNEL_F64(k_mul_f64, "v_mul_f64 %0, %0, %1")
+DEFINE_KERNEL_F64(k_max_f64, "v_max_f64 %0, %0, %1")
+DEFINE_KERNEL_F64(k_min_f64, "v_min_f64 %0, %0, %1")
+DEFINE_KERNEL_F64(k_rcp_f64, "v_rcp_f64 %0, %0")
+DEFINE_KERNEL_F64(k_sqrt_f64, "v_sqrt_f64 %0, %0")
+DEFINE_KERNEL_F64(k_rsq_f64, "v_rsq_f64 %0, %0")
+// v_mad_u64_u32 (Philox's 32x32->64 multiply): 64-bit accumulator, 32-bit factors
+__global__ __launch_bounds__(256) void k_mad_u64_u32(double* out, unsigned long long* cycles, double b, double c) {
+    unsigned long long a[kUnroll];
+    const unsigned int f0 = (unsigned int)(b * 1e6) | 1u, f1 = (unsigned int)(c * 1e12) | 3u;
+    for (int k = 0; k < kUnroll; k++) a[k] = threadIdx.x + k;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < kIters; it++) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k]) : "v"(f0), "v"(f1) : "vcc");
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    unsigned long long s = 0; for (int k = 0; k < kUnroll; k++) s += a[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (double)s;
+    if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+DEFINE_KERNEL_F64(k_cmp_f64, "v_cmp_lt_f64 vcc, %0, %1")
+DEFINE_KERNEL_F64(k_div_fixup_f64, "v_div_fixup_f64 %0, %0, %1, %2")
+DEFINE_KERNEL_F64(k_mov_b64, "v_mov_b64 %0, %1")
+
+// The chip idles at a low clock and needs milliseconds of sustained load to reach its full clock, so every measurement is
+// kReps back-to-back launches of which only the last kTimed are timed; cycles are wall time x the nominal 2.4 GHz (the
+// shader-clock counter is reported next to it: it ticks at a fixed rate, not at the momentary clock).
+constexpr int kReps = 24, kTimed = 8;
+constexpr double kNominalGHz = 2.4;
+template <typename T, typename K>
+void run(const char* name, K kernel, int waves_per_simd, T* d_out, unsigned long long* d_cycles, int n_cus) {
+    const int grid = n_cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD; waves_per_simd blocks per CU
+    std::vector<unsigned long long> cyc((size_t)grid * 4);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int r = 0; r < kReps; r++) {
+        if (r == kReps - kTimed) CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, 0, d_out, d_cycles, (T)1.0000001, (T)1e-9);
+    }
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= (float)kTimed;
+    CHECK(hipMemcpy(cyc.data(), d_cycles, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean = 0;
+    for (unsigned long long c : cyc) mean += (double)c;
+    mean /= (double)cyc.size();
+    const double insts = (double)kUnroll * kIters;
+    const double wall_cycles = (double)ms * 1e-3 * kNominalGHz * 1e9;
+    std::printf("%-16s waves/SIMD %d: %.2f cycles per wave-instruction per SIMD (launch wall time x 2.4 GHz; shader-clock counter inside the wave: %.2f); %.1f Ginstr/s chip-wide; launch %.3f ms\n",
+                name, waves_per_simd, wall_cycles / (insts * waves_per_simd), mean / (insts * waves_per_simd), insts * waves_per_simd * 4.0 * n_cus / (ms * 1e-3) / 1e9, ms);
+    CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int n_cus = prop.multiProcessorCount;
+    std::printf("# %s, %d CUs, clock %.0f MHz; %d x %d independent instructions per wave\n", prop.name, n_cus, prop.clockRate / 1e3, kIters, kUnroll);
+    double* d_out;
+    unsigned long long* d_cycles;
+    CHECK(hipMalloc(&d_out, (size_t)n_cus * 8 * 256 * sizeof(double)));
+    CHECK(hipMalloc(&d_cycles, (size_t)n_cus * 8 * 4 * sizeof(unsigned long long)));
+    for (int w : {1, 4, 8}) {
+#define RUN32(k) run<float>(#k, k, w, reinterpret_cast<float*>(d_out), d_cycles, n_cus)
+#define RUN64(k) run<double>(#k, k, w, d_out, d_cycles, n_cus)
+        RUN32(k_fma_f32); RUN32(k_add_f32); RUN32(k_max_f32); RUN32(k_rcp_f32); RUN32(k_sqrt_f32); RUN32(k_sin_f32); RUN32(k_mul_lo_u32); RUN32(k_xor_b32);
+        RUN64(k_fma_f64); RUN64(k_add_f64); RUN64(k_mul_f64); RUN64(k_max_f64); RUN64(k_min_f64); RUN64(k_rcp_f64); RUN64(k_sqrt_f64); RUN64(k_rsq_f64);
+        RUN64(k_mad_u64_u32); RUN64(k_cmp_f64); RUN64(k_div_fixup_f64); RUN64(k_mov_b64);
+    }
+    return 0;
+}
