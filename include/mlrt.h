@@ -194,10 +194,12 @@ typedef struct mlrt_options {
     int32_t tail[8];       /* samples of the tapering passes, counted from the end of a pixel's sample range */
     int32_t stats;         /* debug library only: in-kernel counters */
     int32_t debug_pixel, debug_sample; /* debug library only: print the path of one (pixel, sample); -1 = off */
+    int32_t stall_cap;     /* 0: default.  Kernel-loop iterations a wave may spend without finishing a path before the render
+                            * kernel's watchdog makes it give up (mlrt_context_check) */
 } mlrt_options;
 void mlrt_options_default(mlrt_options* out);
 /* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,
- * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_CULL_F64, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL):
+ * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_CULL_F64, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL, MLRT_STALL_CAP):
  * the only place the library reads its environment. */
 void mlrt_options_from_env(mlrt_options* out);
 
@@ -219,12 +221,22 @@ void mlrt_context_destroy(mlrt_context* ctx);
 int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* rows,
                             int32_t n_rows, int32_t* rgb_out, mlrt_progress_fn progress, void* user);
 
-/* Asynchronous device-resident form used for benchmarking and multi-GPU runs: `d_rows` (may be NULL = all
- * rows) and `d_rgb_out` [n_rows][W][3] int32 are DEVICE pointers on the context's device; `d_accum_out` is an
- * optional device array [n_rows][W][3] of f64 colour sums (NULL to skip).  The kernel is enqueued on
- * `hip_stream` (a hipStream_t, NULL = default stream) and the call returns without synchronising. */
+/* Asynchronous device-resident form used for benchmarking and multi-GPU runs: `d_rows` (n_rows row indices; NULL
+ * = the rows 0..n_rows-1, so pass n_rows = image_height for the whole frame) and `d_rgb_out` [n_rows][W][3] int32 are
+ * DEVICE pointers on the context's device; `d_accum_out` is an optional device array [n_rows][W][3] of f64 colour sums
+ * (NULL to skip).  n_rows == 0 renders nothing.  The kernels are enqueued on `hip_stream` (a hipStream_t, NULL = default
+ * stream) and the call returns without synchronising.
+ * ONE frame in flight per context: the accumulation buffer, the tile counters and the timing events are per-context
+ * scratch, so successive calls on one context must use the same stream (or be synchronised by the caller); use one
+ * context per stream for concurrent frames (mlrt_multi does).  A frame is limited to n_rows * W * 3 < 2^31 values. */
 int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* d_rows,
                                    int32_t n_rows, int32_t* d_rgb_out, double* d_accum_out, void* hip_stream);
+
+/* Waits for the context's last launch and reports its health: the render kernel's persistent waves leave their loop
+ * only when every lane is idle, so a kernel-side bug could spin forever; a watchdog in the loop makes a wave that has not
+ * finished a single path for ~2^24 iterations give up instead.  MLRT_ERR_HIP + a message naming the lanes' states if that
+ * happened (the frame is then incomplete), MLRT_OK otherwise.  mlrt_context_render and mlrt_multi_render call it. */
+int32_t mlrt_context_check(mlrt_context* ctx);
 
 /* Time of the most recent render kernel of this context in milliseconds, measured with HIP events on the
  * launch stream (synchronises on the stop event). Negative if nothing was launched. */
@@ -233,6 +245,36 @@ double mlrt_context_last_kernel_ms(mlrt_context* ctx);
 /* Introspection for tests and DESIGN.md: bytes of the packed device scene, whether it is staged in LDS,
  * threads per workgroup, workgroups launched. out[4]. */
 int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]);
+
+/* ---- several GPUs of one node, one process --------------------------------------------------------
+ * The rows of the frame are dealt to the devices round-robin (the analogue of the reference's one-task-per-row
+ * into_par_iter, /root/reference/src/raytrace.rs:172-186, with the devices as workers), every device renders its rows
+ * from its own copy of the scene on its own stream, and ONE gather of the finished rows (one byte per channel) to
+ * devices[0] closes the frame: RCCL over xGMI (grouped ncclSend / ncclRecv; librccl.so is loaded on first use) or, for
+ * device lists with repeats - a rehearsal of the N-device path on fewer GPUs, which cannot form a communicator -
+ * hipMemcpyPeerAsync.  The frame is bit-identical for any device list (Philox keyed per (pixel, sample), integer
+ * accumulation). */
+enum { MLRT_GATHER_AUTO = 0, /* RCCL when the devices are distinct and more than one, else copies */
+       MLRT_GATHER_RCCL = 1, /* always RCCL (distinct devices; on ONE device the root's rows are sent to itself: a test of the wire) */
+       MLRT_GATHER_COPY = 2  /* hipMemcpyPeerAsync */ };
+typedef struct mlrt_multi mlrt_multi;
+/* The row plan: the rows device k of n renders (j = k, k + n, ...; row 0 = bottom), written to rows_out when not NULL.
+ * Returns their number.  Pure host arithmetic. */
+int32_t mlrt_rows_for_device(int32_t image_height, int32_t k, int32_t n_devices, int32_t* rows_out);
+/* One context and one stream per entry of `devices`.  options == NULL: mlrt_options_from_env(). */
+int32_t mlrt_multi_create(const mlrt_scene* scene, const int32_t* devices, int32_t n_devices, int32_t precision, const mlrt_options* options,
+                          int32_t gather_mode, mlrt_multi** out);
+void mlrt_multi_destroy(mlrt_multi* multi);
+/* Replaces Renderer::render: the whole frame into rgb_out, host [H][W][3] int32, row 0 = bottom.  Blocks until done;
+ * `progress` is called on the calling thread as devices finish. */
+int32_t mlrt_multi_render(mlrt_multi* multi, const mlrt_camera* camera, const mlrt_params* params, int32_t* rgb_out, mlrt_progress_fn progress,
+                          void* user);
+/* Of the last frame: wall milliseconds of mlrt_multi_render, the render-kernel milliseconds of every device (HIP events;
+ * array of n_devices) and the gather actually used (MLRT_GATHER_RCCL or MLRT_GATHER_COPY).  Any pointer may be NULL. */
+int32_t mlrt_multi_info(mlrt_multi* multi, double* frame_ms, double* kernel_ms_per_device, int32_t* gather_used);
+/* One-shot: create (options from the environment, MLRT_GATHER_AUTO) + render + destroy. */
+int32_t mlrt_render_multi(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision,
+                          const int32_t* devices, int32_t n_devices, int32_t* rgb_out, mlrt_progress_fn progress, void* user);
 
 /* One-shot drop-in for main.rs:147-157: create + render all rows + destroy. */
 int32_t mlrt_render(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision,

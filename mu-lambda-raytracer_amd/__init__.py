@@ -18,6 +18,7 @@ EARTHMAP_PPM = os.path.join(os.path.dirname(_HERE), "assets", "earthmap.ppm")
 
 MLRT_OK, MLRT_ERR_INVALID, MLRT_ERR_NO_DEVICE, MLRT_ERR_HIP, MLRT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 PRECISION_FP32, PRECISION_FP64, PRECISION_FP64_STRICT = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
 BG_BLACK, BG_GRADIENT = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 PRIM_SPHERE, PRIM_BOX, PRIM_RECT = 0, 1, 2
@@ -106,7 +107,7 @@ class Options(C.Structure):
     """mlrt_options (include/mlrt.h): tuning / diagnostic switches, none of which may change an f64 image."""
     _fields_ = [("sah", C.c_int32), ("leaf_wrap", C.c_int32), ("primary_lists", C.c_int32), ("lds_scene", C.c_int32), ("force_full", C.c_int32), ("cull_f64", C.c_int32),
                 ("tile_samples", C.c_int32), ("tile_queues", C.c_int32), ("n_tail", C.c_int32), ("tail", C.c_int32 * 8), ("stats", C.c_int32),
-                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32)]
+                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
@@ -114,7 +115,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
 # every symbol declared in include/mlrt.h and include/mlrt_host.h
 EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_options_default", "mlrt_options_from_env", "mlrt_context_create",
                   "mlrt_context_create_opts", "mlrt_context_destroy", "mlrt_context_render",
-                  "mlrt_context_render_device", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_render"]
+                  "mlrt_context_render_device", "mlrt_context_check", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_render", "mlrt_rows_for_device", "mlrt_multi_create",
+                  "mlrt_multi_destroy", "mlrt_multi_render", "mlrt_multi_info", "mlrt_render_multi"]
 EXPORTS_MLRT_HOST_H = ["mlrt_world_count", "mlrt_world_name", "mlrt_world_build", "mlrt_world_free", "mlrt_world_scene", "mlrt_world_camera",
                        "mlrt_world_background", "mlrt_world_stream_probes", "mlrt_camera_new", "mlrt_image_height", "mlrt_write_p3",
                        "mlrt_write_p3_path", "mlrt_pcg64_stream", "mlrt_decode_jpeg", "mlrt_decode_jpeg_file", "mlrt_free"]
@@ -153,10 +155,17 @@ def lib():
         L.mlrt_context_destroy.argtypes = [C.c_void_p]
         L.mlrt_context_render.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mlrt_context_render_device.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mlrt_context_check.argtypes = [C.c_void_p]
         L.mlrt_context_last_kernel_ms.restype = C.c_double
         L.mlrt_context_last_kernel_ms.argtypes = [C.c_void_p]
         L.mlrt_context_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.mlrt_render.argtypes = [C.POINTER(Scene), C.POINTER(CameraStruct), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mlrt_rows_for_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.mlrt_multi_create.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(Options), C.c_int32, C.POINTER(C.c_void_p)]
+        L.mlrt_multi_destroy.argtypes = [C.c_void_p]
+        L.mlrt_multi_render.argtypes = [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mlrt_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.mlrt_render_multi.argtypes = [C.POINTER(Scene), C.POINTER(CameraStruct), C.POINTER(Params), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -313,6 +322,10 @@ class Renderer:
         _check(lib().mlrt_context_render_device(self.ctx, C.byref(self.camera), C.byref(self.params), d_rows_ptr, int(n_rows), d_rgb_ptr, d_accum_ptr,
                                                 stream))
 
+    def check(self):
+        """Waits for the last launch; raises if the render kernel's watchdog tripped."""
+        _check(lib().mlrt_context_check(self.ctx))
+
     def last_kernel_ms(self):
         return float(lib().mlrt_context_last_kernel_ms(self.ctx))
 
@@ -325,6 +338,48 @@ class Renderer:
         if getattr(self, "ctx", None):
             lib().mlrt_context_destroy(self.ctx)
             self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rows_for_device(image_height, k, n_devices):
+    """mlrt_rows_for_device: the rows device k of n renders (round-robin)."""
+    out = (C.c_int32 * max(1, int(image_height)))()
+    n = lib().mlrt_rows_for_device(int(image_height), int(k), int(n_devices), out)
+    return [int(out[i]) for i in range(n)]
+
+
+class MultiRenderer:
+    """mlrt_multi_*: one frame over several GPUs from one process (one context and stream per device, one gather)."""
+
+    def __init__(self, world, camera, params, devices, precision=PRECISION_FP64, gather=GATHER_AUTO, opts=None):
+        self.world, self.camera, self.params, self.devices = world, camera, params, list(devices)
+        dev = (C.c_int32 * len(self.devices))(*self.devices)
+        handle = C.c_void_p()
+        _check(lib().mlrt_multi_create(world.scene, dev, len(self.devices), int(precision), C.byref(opts) if opts is not None else None, int(gather), C.byref(handle)))
+        self.handle = handle
+
+    def render(self, progress=None):
+        p = self.params
+        out = np.zeros((p.image_height, p.image_width, 3), dtype=np.int32)
+        cb = PROGRESS_FN(progress) if progress else None
+        _check(lib().mlrt_multi_render(self.handle, C.byref(self.camera), C.byref(p), out.ctypes.data_as(C.c_void_p), C.cast(cb, C.c_void_p) if cb else None, None))
+        return out
+
+    def info(self):
+        frame_ms, gather = C.c_double(), C.c_int32()
+        kernel_ms = (C.c_double * len(self.devices))()
+        _check(lib().mlrt_multi_info(self.handle, C.byref(frame_ms), kernel_ms, C.byref(gather)))
+        return {"frame_ms": frame_ms.value, "kernel_ms": list(kernel_ms), "gather": int(gather.value)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().mlrt_multi_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:

@@ -60,6 +60,8 @@ UNITS = [
     ("kernel_f64s.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256",
                                "-DMLRT_LEAN_WAVES_PER_EU=1", "-DMLRT_FULL_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
     ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
+    ("multi.o", os.path.join(HERE, "csrc", "mlrt_multi.cpp"), []),
+    ("multi_kernels.o", os.path.join(HERE, "csrc", "mlrt_multi_kernels.hip"), ["--offload-arch=" + ARCH]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),
     ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),
     ("jpeg.o", os.path.join(HERE, "host", "jpeg_baseline.cpp"), ["-ffp-contract=off"]),
@@ -97,7 +99,7 @@ def build(force=False, verbose_resources=False):
         with ThreadPoolExecutor(max_workers=min(len(cmds), int(os.environ.get("MLRT_BUILD_JOBS", "6")))) as pool:
             list(pool.map(_run, cmds))
     if force or _stale(LIB, objs):
-        _run([HIPCC, "-shared", "-fPIC", "-o", LIB] + objs)
+        _run([HIPCC, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])  # (librccl.so is dlopen'ed by the multi-device gather, not linked)
     main_src = os.path.join(HERE, "host", "main.cpp")
     if TAG:
         return LIB

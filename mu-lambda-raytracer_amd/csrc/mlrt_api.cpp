@@ -536,6 +536,7 @@ struct mlrt_context {
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
+    unsigned int* d_status = nullptr;  // watchdog record of the render kernel (KParams::status)
     uint16_t* d_cand = nullptr;  // primary candidate records, [cand_groups][16]
     size_t cand_groups = 0;
     unsigned long long* d_stats = nullptr;
@@ -559,6 +560,7 @@ void destroy(mlrt_context* c) {
     for (unsigned char* p : c->d_image_pixels) (void)hipFree(p);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_cand) (void)hipFree(c->d_cand);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_acc) (void)hipFree(c->d_acc);
@@ -679,6 +681,11 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.acc_global = c->d_acc;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
     K.tile_counter = c->d_tile_counter;
+    K.status = c->d_status;
+    // 2^24 iterations (seconds) without a finished path; a path may legitimately bounce max_depth times (a handful of iterations
+    // per bounce), so absurd depths switch the watchdog off rather than risk a false alarm
+    K.stall_cap = p->max_depth > (1 << 20) ? 0xFFFFFFFFu : (1u << 24);
+    if (c->opt.stall_cap > 0) K.stall_cap = (uint32_t)c->opt.stall_cap;
     K.n_queues = c->opt.tile_queues;
     K.stats = c->d_stats;
     K.primary_lists = primary_lists_wanted(c, p) ? c->d_cand : nullptr;
@@ -791,7 +798,7 @@ void mlrt_options_default(mlrt_options* o) {
     std::memset(o, 0, sizeof *o);
     o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0;
     o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
-    o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0;
+    o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0; o->stall_cap = 0;
 }
 // The MLRT_* environment variables (A/B scripts under tools/): read here and nowhere else, once per context.
 void mlrt_options_from_env(mlrt_options* o) {
@@ -815,6 +822,7 @@ void mlrt_options_from_env(mlrt_options* o) {
         }
     }
     if (std::getenv("MLRT_STATS")) o->stats = 1;
+    if (const char* sc = std::getenv("MLRT_STALL_CAP")) o->stall_cap = std::atoi(sc);
     if (const char* dbg = std::getenv("MLRT_DEBUG_PIXEL")) { int a = -1, b = 0; if (std::sscanf(dbg, "%d,%d", &a, &b) >= 1) { o->debug_pixel = a; o->debug_sample = b; } }
 }
 
@@ -891,6 +899,8 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         }
         MLRT_HIP(hipMalloc(&c->d_tile_counter, mlrt::kMaxQueues * 64));
         MLRT_HIP(hipMemset(c->d_tile_counter, 0, mlrt::kMaxQueues * 64));  // (every frame's resolve kernel leaves them zero again)
+        MLRT_HIP(hipMalloc(&c->d_status, 68 * sizeof(unsigned int)));
+        MLRT_HIP(hipMemset(c->d_status, 0, 68 * sizeof(unsigned int)));
         if (options->stats || options->debug_pixel >= 0) {
             const bool instrumented = c->build->instrumented() != 0;
             if (!instrumented) {
@@ -951,8 +961,9 @@ int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const 
         MLRT_HIP(hipMalloc(&d_rows, (size_t)n_rows * sizeof(int32_t)));
         MLRT_HIP(hipMalloc(&d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t)));
         MLRT_HIP(hipMemcpy(d_rows, host_rows.data(), (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
-        // with a progress callback the image is rendered in bands so the caller sees rows complete
-        const int32_t bands = progress ? std::min<int32_t>(n_rows, 16) : 1;
+        // with a progress callback the image is rendered in a few bands so the caller sees rows complete (each band is a
+        // synchronised launch with its own queue tail: four cost ~3 % of a C2 frame, sixteen cost ~15 %); without one: one launch
+        const int32_t bands = progress ? std::min<int32_t>(n_rows, 4) : 1;
         int32_t done = 0;
         for (int32_t b = 0; b < bands; b++) {
             const int32_t begin = (int32_t)((int64_t)n_rows * b / bands), end = (int32_t)((int64_t)n_rows * (b + 1) / bands);
@@ -963,10 +974,31 @@ int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const 
             if (progress) progress(done, n_rows, user);
         }
         MLRT_HIP(hipMemcpy(rgb_out, d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (mlrt_context_check(ctx) != MLRT_OK) throw Fail{MLRT_ERR_HIP, std::string(mlrt_last_error())};
     });
     if (d_rows) (void)hipFree(d_rows);
     if (d_rgb) (void)hipFree(d_rgb);
     return rc;
+}
+
+int32_t mlrt_context_check(mlrt_context* ctx) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx, "context is NULL");
+        MLRT_HIP(hipSetDevice(ctx->device));
+        if (ctx->timed) MLRT_HIP(hipEventSynchronize(ctx->ev_stop));
+        unsigned int st[68];
+        MLRT_HIP(hipMemcpy(st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] == 0u) return;
+        MLRT_HIP(hipMemset(ctx->d_status, 0, sizeof st));
+        static const char* kPhase[] = {"trav", "special", "shade", "idle", "wait"};
+        std::string lanes;
+        for (int l = 0; l < 64; l++) {
+            const unsigned int ph = st[4 + l] & 0xFFu;
+            lanes += std::string(l ? " " : "") + (ph < 5 ? kPhase[ph] : "?") + ((st[4 + l] >> 8) & 1u ? "*" : "") + "@" + std::to_string(st[4 + l] >> 16);
+        }
+        throw Fail{MLRT_ERR_HIP, "render kernel watchdog: " + std::to_string(st[0]) + " wave(s) made no progress and gave up (last: workgroup " + std::to_string(st[1]) +
+                                     ", wave " + std::to_string(st[2]) + "); the frame is incomplete.  Lane phases (* = holds a path, @entry): " + lanes};
+    });
 }
 
 double mlrt_context_last_kernel_ms(mlrt_context* ctx) {

@@ -136,6 +136,8 @@ struct KParams {
     double* accum_out;    // optional [n_rows][W][3]
     unsigned int* tile_counter;  // [n_queues] counters, 64 bytes apart
     int32_t n_queues;            // power of two <= kMaxQueues
+    unsigned int* status;        // [4 + 64]: watchdog record (waves that gave up, workgroup, wave, -, then the lanes' phases), zero when all is well
+    uint32_t stall_cap;          // kernel-loop iterations a wave may spend without finishing a path before it gives up
     unsigned long long* stats;  // optional [8]: iterations, trav lane-steps, special batches, special lanes, shade batches, shade lanes, samples, tiles
     const uint16_t* primary_lists;  // or nullptr; sphere-only scene + pinhole camera: [n_groups][16] per-pixel-group candidate records (mlrt_primary_lists_kernel):
                                     // a group's primary rays test those entries instead of walking the BVH

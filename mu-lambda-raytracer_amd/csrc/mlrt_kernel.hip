@@ -1239,6 +1239,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     unsigned long long st_c_end = 0, st_c_regen = 0, st_c1 = 0;  // MLRT_STATS: within the shading batch: paths ended/scattered, regeneration (the rest: new-ray setup)
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
+    unsigned int stall = 0u;  // wave-uniform: iterations since a path of this wave last ended
     int phase = PH_SHADE;  // every lane starts by asking for a sample
     bool has_path = false;
     int pix = 0, depth = 0;  // pix: the lane's bank << kPixBankShift | index of its pixel's first sum in acc
@@ -1416,6 +1417,7 @@ void mlrt_render_kernel(const KParams<real> P) {
             for (;;) {
                 const unsigned long long need = __ballot(want);
                 if (need == 0ull) break;
+                stall = 0u;  // a path of this wave has ended: the wave makes progress (watchdog below)
                 if (MLRT_RARELY(t_next >= t_total)) {
                     // open the next tile into ANY bank whose previous tile has fully drained (not the next of a ring: one
                     // 50-bounce path would hold its bank, and with it the whole ring, while the other lanes run out of samples)
@@ -1507,6 +1509,18 @@ void mlrt_render_kernel(const KParams<real> P) {
         }
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_shade += t - st_c0; }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
+        // Watchdog: the loop ends when every lane is idle, so a slip in the lane state machine (round 1 had one: lanes parked
+        // in PH_WAIT that nothing woke) would spin forever and take the GPU with it.  A wave that has not finished a single
+        // path for stall_cap iterations (seconds; a legitimate path is a few hundred) records what its lanes were doing
+        // and leaves: the launch ends, the host reports MLRT_ERR_HIP (mlrt_context_check) instead of a wedged device.
+        if (MLRT_RARELY(++stall > P.stall_cap)) {
+            if (lane == 0) {
+                atomicAdd(&P.status[0], 1u);  // waves that gave up
+                P.status[1] = (unsigned int)blockIdx.x; P.status[2] = (unsigned int)wave;
+            }
+            P.status[4 + lane] = (unsigned int)phase | ((unsigned int)has_path << 8) | ((unsigned int)(c.node & 0xFFFF) << 16);  // (of the last such wave)
+            break;
+        }
     }
     flush_finished_banks();  // (max_depth == 0 finishes its last samples inside the regeneration loop)
     if (MLRT_STATS_ON(P) && lane == 0) {

@@ -188,11 +188,15 @@ struct Decoder {
             const uint8_t* seg = p;
             const uint8_t* seg_end = p + (len - 2);
             p = seg_end;
+            // every field below is read only after its bytes are known to lie inside the segment (a truncated or lying
+            // segment length must fail, not read past the buffer)
+            auto need = [&](ptrdiff_t bytes) { return seg_end - seg >= bytes; };
             if (m == 0xDB) {  // DQT
                 while (seg < seg_end) {
                     const int pq = seg[0] >> 4, tq = seg[0] & 15;
                     seg++;
                     if (tq > 3) return fail("bad quantisation table id");
+                    if (!need(pq ? 128 : 64)) return fail("bad segment length (DQT)");
                     for (int i = 0; i < 64; i++) {
                         if (pq) { qt[tq][i] = (uint16_t)((seg[0] << 8) | seg[1]); seg += 2; } else { qt[tq][i] = *seg++; }
                     }
@@ -203,6 +207,7 @@ struct Decoder {
                     const int tc = seg[0] >> 4, th = seg[0] & 15;
                     seg++;
                     if (th > 3 || tc > 1) return fail("bad Huffman table id");
+                    if (!need(16)) return fail("bad segment length (DHT)");
                     uint8_t counts[16];
                     int n = 0;
                     for (int i = 0; i < 16; i++) { counts[i] = seg[i]; n += seg[i]; }
@@ -212,11 +217,14 @@ struct Decoder {
                     seg += n;
                 }
             } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1 (Huffman, sequential)
+                if (!need(6)) return fail("bad segment length (SOF)");
                 if (seg[0] != 8) return fail("only 8-bit JPEG is supported");
                 height = (seg[1] << 8) | seg[2];
                 width = (seg[3] << 8) | seg[4];
                 const int n = seg[5];
                 if ((n != 1 && n != 3) || width <= 0 || height <= 0) return fail("unsupported component count or size");
+                if (!need(6 + 3 * n)) return fail("bad segment length (SOF components)");
+                if ((int64_t)width * height > (int64_t)1 << 28) return fail("image too large");
                 comps.assign((size_t)n, Component());
                 for (int i = 0; i < n; i++) {
                     comps[(size_t)i].id = seg[6 + 3 * i];
@@ -230,11 +238,14 @@ struct Decoder {
             } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
                 return fail("progressive / lossless / arithmetic JPEG is not supported (baseline only)");
             } else if (m == 0xDD) {  // DRI
+                if (!need(2)) return fail("bad segment length (DRI)");
                 restart_interval = (seg[0] << 8) | seg[1];
             } else if (m == 0xDA) {  // SOS
                 if (!got_frame) return fail("scan before frame header");
+                if (!need(1)) return fail("bad segment length (SOS)");
                 const int n = seg[0];
                 if (n != (int)comps.size()) return fail("only single-scan (interleaved) baseline files are supported");
+                if (!need(1 + 2 * n + 3)) return fail("bad segment length (SOS components)");
                 for (int i = 0; i < n; i++) {
                     bool found = false;
                     for (Component& c : comps)
@@ -281,15 +292,20 @@ extern "C" {
 
 int32_t mlrt_decode_jpeg(const uint8_t* data, int64_t size, uint8_t** rgb_out, int32_t* width, int32_t* height) {
     if (!data || size < 4 || !rgb_out || !width || !height) { mlrt::set_last_error("mlrt_decode_jpeg: bad argument"); return MLRT_ERR_INVALID; }
-    Decoder d;
-    d.p = data; d.end = data + size;
-    std::vector<uint8_t> rgb;
-    if (!d.run(rgb)) { mlrt::set_last_error("mlrt_decode_jpeg: " + d.error); return MLRT_ERR_UNSUPPORTED; }
-    uint8_t* out = static_cast<uint8_t*>(std::malloc(rgb.size()));
-    if (!out) { mlrt::set_last_error("mlrt_decode_jpeg: out of memory"); return MLRT_ERR_INVALID; }
-    std::memcpy(out, rgb.data(), rgb.size());
-    *rgb_out = out; *width = d.width; *height = d.height;
-    return MLRT_OK;
+    try {  // (no exception may cross the C ABI: a header announcing 65535 x 65535 pixels must not end in std::bad_alloc)
+        Decoder d;
+        d.p = data; d.end = data + size;
+        std::vector<uint8_t> rgb;
+        if (!d.run(rgb)) { mlrt::set_last_error("mlrt_decode_jpeg: " + d.error); return MLRT_ERR_UNSUPPORTED; }
+        uint8_t* out = static_cast<uint8_t*>(std::malloc(rgb.size()));
+        if (!out) { mlrt::set_last_error("mlrt_decode_jpeg: out of memory"); return MLRT_ERR_INVALID; }
+        std::memcpy(out, rgb.data(), rgb.size());
+        *rgb_out = out; *width = d.width; *height = d.height;
+        return MLRT_OK;
+    } catch (const std::exception& e) {
+        mlrt::set_last_error(std::string("mlrt_decode_jpeg: ") + e.what());
+        return MLRT_ERR_INVALID;
+    }
 }
 
 int32_t mlrt_decode_jpeg_file(const char* path, uint8_t** rgb_out, int32_t* width, int32_t* height) {

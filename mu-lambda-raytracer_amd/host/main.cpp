@@ -3,8 +3,12 @@
 // Mirrors /root/reference/src/main.rs: args() :64-132 (same flag names and defaults), do_it() :181-207 (world from
 // rng(0), camera), do_tracing() :134-180 (P3 header, render, "Rendered in X s" on stderr, rows top to bottom).
 // The render itself is mlrt_context_render (include/mlrt.h) on the MI355X; there is no CPU path here.
-// Flags beyond the reference: --precision=fp32|fp64, --device=N, --earthmap=<earthmap.jpg or a binary P6> (default:
-// earthmap.jpg in the working directory, as the reference; then earthmap.ppm).
+// Flags beyond the reference: --precision=fp64|fp32 (default fp64: the reference's arithmetic, /root/reference/src/vec.rs:5-8;
+// fp32 is the fast mixed-precision mode), --device=N, --gpus=N (the frame's rows over devices 0..N-1 of this node, one
+// gather: mlrt_multi_*) or --devices=a,b,c, --format=p3|p6 (p6: the same image as binary PPM), --earthmap=<earthmap.jpg or a
+// binary P6> (default: earthmap.jpg in the working directory, as the reference; then earthmap.ppm).
+// Progress ("Remaining: NN%", main.rs:157-173) is shown only when stderr is a terminal: it splits the frame into a few
+// synchronised launches, which a timed or piped run should not pay for.
 // Not supported: running without --seed and --randomized_rendering (ThreadRng, non-deterministic).
 //
 // Frame-sequence mode (replaces /root/reference/movie.py, which re-launches the binary - world rebuild and all - once
@@ -12,6 +16,8 @@
 // frames with the camera orbiting `movie_origin` exactly as movie.py:56-69 moves it (lookat = origin, lookfrom = origin +
 // the start offset with its polar angle advanced by step degrees per frame) and writes <prefix>NNNN.ppm.  The world,
 // the packed scene and the device context stay resident; only the camera changes.
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -70,8 +76,8 @@ int fail(const char* what) {
 
 int main(int argc, char** argv) {
     std::map<std::string, std::string> opt = {{"aspect_ratio", "16:9"}, {"image_width", "400"}, {"samples_per_pixel", "200"}, {"max_depth", "50"},
-                                              {"up", "0,1.0,0"},        {"aperture", "0.0"},    {"world", "simple"},          {"precision", "fp32"},
-                                              {"device", "0"}};
+                                              {"up", "0,1.0,0"},        {"aperture", "0.0"},    {"world", "simple"},          {"precision", "fp64"},
+                                              {"device", "0"},          {"format", "p3"}};
     for (int i = 1; i < argc; i++) {
         std::string a(argv[i]);
         if (a == "--randomized_rendering" || a == "-r") { std::fprintf(stderr, "mlrt: --randomized_rendering (ThreadRng) is not supported by the device path\n"); return 2; }
@@ -149,8 +155,33 @@ int main(int argc, char** argv) {
     mlrt_camera camera;
     mlrt_camera_new(lookfrom, lookat, up, fov, aspect_ratio, std::atof(opt["aperture"].c_str()), focus_dist, &camera);
 
+    if (opt["precision"] != "fp64" && opt["precision"] != "fp32") { std::fprintf(stderr, "mlrt: --precision must be fp64 or fp32\n"); return 2; }
+    if (opt["format"] != "p3" && opt["format"] != "p6") { std::fprintf(stderr, "mlrt: --format must be p3 or p6\n"); return 2; }
     const int32_t precision = opt["precision"] == "fp64" ? MLRT_PRECISION_FP64 : MLRT_PRECISION_FP32;
     std::vector<int32_t> rgb((size_t)params.image_width * params.image_height * 3);
+    std::vector<int32_t> devices;  // --gpus=N | --devices=a,b,c: the multi-device path
+    if (opt.count("devices")) {
+        for (const char* q = opt["devices"].c_str(); *q;) {
+            devices.push_back(std::atoi(q));
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    } else if (opt.count("gpus")) {
+        const int n = std::atoi(opt["gpus"].c_str());
+        if (n < 1 || n > mlrt_device_count()) { std::fprintf(stderr, "mlrt: --gpus=%d but %d device(s) are visible\n", n, (int)mlrt_device_count()); return 2; }
+        for (int k = 0; k < n; k++) devices.push_back(k);
+    }
+    auto write_image = [&](FILE* f) -> int32_t {
+        if (opt["format"] == "p3") return mlrt_write_p3(f, rgb.data(), params.image_width, params.image_height);
+        // binary PPM of the same image, top row first (the reference prints P3 only, main.rs:144,175-179)
+        std::fprintf(f, "P6\n%d %d\n255\n", params.image_width, params.image_height);
+        std::vector<uint8_t> line((size_t)params.image_width * 3);
+        for (int32_t j = params.image_height - 1; j >= 0; j--) {
+            for (size_t e = 0; e < line.size(); e++) line[e] = (uint8_t)rgb[(size_t)j * line.size() + e];
+            if (std::fwrite(line.data(), 1, line.size(), f) != line.size()) return MLRT_ERR_INVALID;
+        }
+        return MLRT_OK;
+    };
 
     if (opt.count("movie_frames")) {
         const int frames = std::atoi(opt["movie_frames"].c_str());
@@ -191,13 +222,21 @@ int main(int argc, char** argv) {
     // pixels together after it - same bytes on stdout.)
     Progress progress;
     progress.start = std::chrono::steady_clock::now();
+    const bool show_progress = isatty(2) != 0;
     mlrt_context* ctx = nullptr;
-    if (mlrt_context_create(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &ctx) != MLRT_OK) return fail("context");
-    if (mlrt_context_render(ctx, &camera, &params, nullptr, 0, rgb.data(), on_progress, &progress) != MLRT_OK) return fail("render");
+    mlrt_multi* multi = nullptr;
+    if (!devices.empty()) {
+        if (mlrt_multi_create(mlrt_world_scene(world), devices.data(), (int32_t)devices.size(), precision, nullptr, MLRT_GATHER_AUTO, &multi) != MLRT_OK) return fail("multi-device context");
+        if (mlrt_multi_render(multi, &camera, &params, rgb.data(), show_progress ? on_progress : nullptr, &progress) != MLRT_OK) return fail("render");
+    } else {
+        if (mlrt_context_create(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &ctx) != MLRT_OK) return fail("context");
+        if (mlrt_context_render(ctx, &camera, &params, nullptr, 0, rgb.data(), show_progress ? on_progress : nullptr, &progress) != MLRT_OK) return fail("render");
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - progress.start).count();
-    std::fprintf(stderr, "\nRendered in %.3fs\n", secs);
-    if (mlrt_write_p3(stdout, rgb.data(), params.image_width, params.image_height) != MLRT_OK) return fail("write");
-    mlrt_context_destroy(ctx);
+    std::fprintf(stderr, "%sRendered in %.3fs\n", show_progress ? "\n" : "", secs);
+    if (write_image(stdout) != MLRT_OK) return fail("write");
+    if (ctx) mlrt_context_destroy(ctx);
+    if (multi) mlrt_multi_destroy(multi);
     mlrt_world_free(world);
     return 0;
 }

@@ -66,3 +66,47 @@ def test_headers_are_valid_c99(tmp_path):
     import subprocess
     src = os.path.join(ROOT, "tests", "c_abi_consumer.c")
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], check=True)
+
+
+def test_row_plan_of_the_multi_device_path(mlrt):
+    """mlrt_rows_for_device (the C-side row plan of mlrt_multi_*): every row to exactly one device, round-robin, the same
+    plan as rowtile.rows_for_rank (the one-process-per-GPU path of bench.py); device 0 holds the most rows."""
+    import importlib
+    rowtile = importlib.import_module("mu-lambda-raytracer_amd.rowtile")
+    for height in (1, 2, 7, 266, 800):
+        for n in (1, 2, 3, 4, 8):
+            seen = []
+            for k in range(n):
+                rows = mlrt.rows_for_device(height, k, n)
+                assert rows == rowtile.rows_for_rank(height, k, n)
+                assert len(rows) <= len(mlrt.rows_for_device(height, 0, n))
+                assert mlrt.lib().mlrt_rows_for_device(height, k, n, None) == len(rows)
+                seen += rows
+            assert sorted(seen) == list(range(height))
+    assert mlrt.lib().mlrt_rows_for_device(10, 3, 3, None) == 0 and mlrt.lib().mlrt_rows_for_device(10, -1, 3, None) == 0
+
+
+def test_multi_device_entry_points_fail_loudly_without_a_device_or_with_bad_arguments(mlrt):
+    w = mlrt.World("random", 42)
+    handle = C.c_void_p()
+    dev = (C.c_int32 * 2)(0, 0)
+    rc = mlrt.lib().mlrt_multi_create(w.scene, dev, 0, mlrt.PRECISION_FP64, None, mlrt.GATHER_AUTO, C.byref(handle))
+    assert rc == mlrt.MLRT_ERR_INVALID and not handle.value
+    rc = mlrt.lib().mlrt_multi_create(w.scene, dev, 2, mlrt.PRECISION_FP64, None, mlrt.GATHER_RCCL, C.byref(handle))
+    assert rc == mlrt.MLRT_ERR_INVALID and b"distinct" in mlrt.lib().mlrt_last_error()
+    if not os.path.exists("/dev/kfd"):
+        rc = mlrt.lib().mlrt_multi_create(w.scene, dev, 1, mlrt.PRECISION_FP64, None, mlrt.GATHER_AUTO, C.byref(handle))
+        assert rc == mlrt.MLRT_ERR_NO_DEVICE and not handle.value
+    w.close()
+
+
+def test_options_defaults_and_environment(mlrt, monkeypatch):
+    o = mlrt.Options()
+    mlrt.lib().mlrt_options_default(C.byref(o))
+    assert (o.sah, o.leaf_wrap, o.primary_lists, o.lds_scene, o.force_full, o.cull_f64) == (1, 1, 1, 1, 0, 0)
+    assert (o.tile_samples, o.tile_queues, o.n_tail, o.stats, o.debug_pixel) == (512, 8, -1, 0, -1)
+    monkeypatch.setenv("MLRT_NO_SAH", "1")
+    monkeypatch.setenv("MLRT_TILE_TAIL", "64,128")
+    monkeypatch.setenv("MLRT_CULL_F64", "1")
+    mlrt.lib().mlrt_options_from_env(C.byref(o))
+    assert o.sah == 0 and o.cull_f64 == 1 and o.n_tail == 2 and list(o.tail)[:2] == [64, 128]

@@ -115,12 +115,26 @@ def test_cli_is_a_drop_in_for_the_reference_command_line(mlrt, oracle, tmp_path)
     px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 400 * 266]], dtype=np.int32).reshape(266, 400, 3)[::-1]
     assert "Rendered in" in out.stderr
     w = mlrt.World("random", 42)
-    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8))
-    assert np.array_equal(px, r.render())
+    # the CLI renders at the reference's precision by default; --precision=fp32 selects the fast mode
+    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8), precision=mlrt.PRECISION_FP64)
+    ref64 = r.render()
+    assert np.array_equal(px, ref64)
     r.close()
-    w.close()
     bad = subprocess.run([mlrt.CLI_PATH, "--world=nope", "--seed=1"], capture_output=True, text=True)
     assert bad.returncode != 0 and "possible values" in bad.stderr
+    # --format=p6: the same image as binary PPM; --gpus=1 / --devices=0,0: the multi-device path (rows over devices, one gather)
+    args = [mlrt.CLI_PATH, "--world=random", "--seed=42", "--aspect_ratio=3:2", "--image_width=400", "--samples_per_pixel=8", "--format=p6"]
+    for extra in ([], ["--gpus=1"], ["--devices=0,0,0"]):
+        raw = subprocess.run(args + extra, capture_output=True, check=True).stdout
+        header = b"P6\n400 266\n255\n"
+        assert raw.startswith(header) and len(raw) == len(header) + 400 * 266 * 3
+        img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(266, 400, 3)[::-1].astype(np.int32)
+        assert np.array_equal(img, ref64), extra
+    fast = subprocess.run(args + ["--precision=fp32"], capture_output=True, check=True).stdout
+    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8), precision=mlrt.PRECISION_FP32)
+    assert np.array_equal(np.frombuffer(fast[len(b"P6\n400 266\n255\n"):], dtype=np.uint8).reshape(266, 400, 3)[::-1].astype(np.int32), r.render())
+    r.close()
+    w.close()
 
 
 def _rmse_vs_golden(img, key):
@@ -266,4 +280,53 @@ def test_primary_candidate_lists_do_not_change_the_image(mlrt, monkeypatch, aper
     r.close()
     monkeypatch.delenv("MLRT_NO_PRIMARY_LISTS")
     assert np.array_equal(with_lists, walked)
+    w.close()
+
+
+@pytest.mark.parametrize("name,width,aspect,spp", [("random", 300, 1.5, 24), ("final_scene", 120, 1.0, 16)])
+def test_multi_device_frame_equals_the_single_context_frame(mlrt, earthmap, name, width, aspect, spp):
+    """mlrt_multi_*: rows dealt round-robin to the entries of the device list, one gather.  On this one-GPU box the list
+    repeats device 0 (copies instead of RCCL: a communicator needs distinct GPUs) - the row plan, the per-device contexts
+    and streams, the byte conversion and the assembly are the code an 8-GPU node runs; and with ONE device RCCL can be forced,
+    which sends the root's rows to itself through ncclSend / ncclRecv (librccl.so loaded on first use)."""
+    w = mlrt.World(name, 42, earthmap if name == "final_scene" else None)
+    height = mlrt.image_height(width, aspect)
+    cam = mlrt.default_camera(w, aspect)
+    params = mlrt.make_params(w, width, height, spp)
+    for precision in (mlrt.PRECISION_FP64, mlrt.PRECISION_FP32):
+        r = mlrt.Renderer(w, cam, params, precision=precision)
+        single = r.render()
+        r.close()
+        for devices, gather in (([0], mlrt.GATHER_AUTO), ([0, 0], mlrt.GATHER_AUTO), ([0] * 8, mlrt.GATHER_COPY), ([0], mlrt.GATHER_RCCL)):
+            m = mlrt.MultiRenderer(w, cam, params, devices, precision=precision, gather=gather)
+            seen = []
+            frame = m.render(progress=lambda done, total, user: seen.append((done, total)))
+            again = m.render()
+            info = m.info()
+            m.close()
+            assert np.array_equal(frame, single), (devices, gather)
+            assert np.array_equal(again, single)
+            assert seen[-1] == (height, height) and info["frame_ms"] > 0 and all(ms > 0 for ms in info["kernel_ms"])
+            assert info["gather"] == (mlrt.GATHER_RCCL if gather == mlrt.GATHER_RCCL else mlrt.GATHER_COPY)
+    w.close()
+
+
+def test_kernel_watchdog_ends_a_stalled_launch_with_an_error(mlrt):
+    """The persistent waves leave the kernel loop only when every lane is idle; a watchdog makes a wave that finishes no path
+    for stall_cap iterations give up, so a state-machine bug is an error message, not a wedged GPU.  Forced here with a cap
+    no real wave can meet (2 iterations); the default cap (2^24) never trips (every other test renders through it)."""
+    w = mlrt.World("random", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    params = mlrt.make_params(w, 96, 64, 64)
+    for precision in (mlrt.PRECISION_FP32, mlrt.PRECISION_FP64):
+        r = mlrt.Renderer(w, cam, params, precision=precision, opts=mlrt.options(stall_cap=2))
+        with pytest.raises(mlrt.MlrtError) as e:
+            r.render()
+        assert e.value.code == mlrt.MLRT_ERR_HIP and "watchdog" in str(e.value) and "Lane phases" in str(e.value)
+        r.close()
+        good = mlrt.Renderer(w, cam, params, precision=precision)
+        img = good.render()
+        good.check()
+        assert img.any()
+        good.close()
     w.close()
