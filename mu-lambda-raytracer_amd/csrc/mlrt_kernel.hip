@@ -118,6 +118,7 @@ struct FrameParams {
     double lens_radius, inv_wm1, inv_hm1;
     MLRT_REAL bg_top[3], bg_bottom[3];
     float through0[3], hor_f[3], ver_f[3], u_f[3], v_f[3];  // fast build: llc - origin, horizontal, vertical, u, v in f32
+    unsigned int stall_cap;                                  // watchdog (see the end of the kernel loop)
 };
 constexpr int kFrameParamBytes = 320;
 static_assert(sizeof(FrameParams) <= kFrameParamBytes, "FrameParams must fit its LDS slot");
@@ -1148,6 +1149,16 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     for (int k = 0; k < kCandRecord / 2; k++) out[k] = (uint32_t)list[2 * k] | ((uint32_t)list[2 * k + 1] << 16);
 }
 
+// KParams::status read from the kernel-argument segment at the point of use (the by-value argument struct sits at its start).
+DEV unsigned int* watchdog_record() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<unsigned int* const volatile*>(args + offsetof(KParams<real>, status));
+#else
+    return nullptr;
+#endif
+}
+
 // The megakernel.  Every lane runs a small state machine over its current path:
 //   PH_TRAV    one cheap step per loop iteration: fetch an entry, slab-test it, follow the skip link
 //   PH_SPECIAL parked on an entry that needs the long code (f64 sphere quadratic, rect, medium, transform bracket)
@@ -1190,6 +1201,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         F.hor_f[threadIdx.x] = (float)P.cam_horizontal[threadIdx.x]; F.ver_f[threadIdx.x] = (float)P.cam_vertical[threadIdx.x];
         F.u_f[threadIdx.x] = (float)P.cam_u[threadIdx.x]; F.v_f[threadIdx.x] = (float)P.cam_v[threadIdx.x];
     }
+    if (threadIdx.x == 0) F.stall_cap = P.stall_cap;
     __syncthreads();
     Scene S;
     S.nodes = reinterpret_cast<const DNode<creal>*>(base + P.off_nodes);
@@ -1239,7 +1251,9 @@ void mlrt_render_kernel(const KParams<real> P) {
     unsigned long long st_c_end = 0, st_c_regen = 0, st_c1 = 0;  // MLRT_STATS: within the shading batch: paths ended/scattered, regeneration (the rest: new-ray setup)
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
 
-    unsigned int stall = 0u;  // wave-uniform: iterations since a path of this wave last ended
+#ifdef MLRT_DEBUG_BUILD
+    unsigned int stall = F.stall_cap;  // wave-uniform countdown: iterations left before watchdog (2) fires, reloaded whenever a path of this wave ends
+#endif
     int phase = PH_SHADE;  // every lane starts by asking for a sample
     bool has_path = false;
     int pix = 0, depth = 0;  // pix: the lane's bank << kPixBankShift | index of its pixel's first sum in acc
@@ -1270,6 +1284,15 @@ void mlrt_render_kernel(const KParams<real> P) {
         return true;
     };
 
+    // A wave that gives up (watchdogs below) records what its lanes were doing.  (The record's address is read from the kernel
+    // arguments only at that point - a volatile load: hoisted out of the loop it would occupy two scalar registers of a kernel
+    // that has none to spare.  A macro, not a lambda: capturing the lane state by reference sent it to scratch.)
+#define MLRT_GIVE_UP()                                                                                                                        \
+    do {                                                                                                                                      \
+        unsigned int* status_ = watchdog_record();                                                                                            \
+        if (lane == 0) { atomicAdd(&status_[0], 1u); status_[1] = (unsigned int)blockIdx.x; status_[2] = (unsigned int)wave; }               \
+        status_[4 + lane] = (unsigned int)phase | ((unsigned int)has_path << 8) | ((unsigned int)(c.node & 0xFFFF) << 16);                  \
+    } while (0)
     DNode<creal> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
     for (;;) {
         // (A) MLRT_STEPS traversal steps between two looks at the batches: the ballots and threshold tests of (B) and (C)
@@ -1352,6 +1375,8 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_special += t - st_c0; st_c0 = t; }
         // (C) batched shading, path termination and regeneration
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
+        // (the end of the loop, below, decided here where the masks are at hand)
+        const bool nobody_runs = (m_trav | m_special | m_shade) == 0ull;
         const bool batch = m_shade != 0ull && (__popcll(m_shade) >= (FEAT == 0 ? MLRT_T_SHADE_LEAN : MLRT_T_SHADE) || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
         if (MLRT_RARELY(batch)) {
             if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
@@ -1417,7 +1442,9 @@ void mlrt_render_kernel(const KParams<real> P) {
             for (;;) {
                 const unsigned long long need = __ballot(want);
                 if (need == 0ull) break;
-                stall = 0u;  // a path of this wave has ended: the wave makes progress (watchdog below)
+#ifdef MLRT_DEBUG_BUILD
+                stall = F.stall_cap;  // a path of this wave has ended: the wave makes progress (watchdog (2) below)
+#endif
                 if (MLRT_RARELY(t_next >= t_total)) {
                     // open the next tile into ANY bank whose previous tile has fully drained (not the next of a ring: one
                     // 50-bounce path would hold its bank, and with it the whole ring, while the other lanes run out of samples)
@@ -1508,19 +1535,22 @@ void mlrt_render_kernel(const KParams<real> P) {
             n = fetch_entry(S, c.node, n_nodes);
         }
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_shade += t - st_c0; }
-        if (__ballot(phase != PH_IDLE) == 0ull) break;
-        // Watchdog: the loop ends when every lane is idle, so a slip in the lane state machine (round 1 had one: lanes parked
-        // in PH_WAIT that nothing woke) would spin forever and take the GPU with it.  A wave that has not finished a single
-        // path for stall_cap iterations (seconds; a legitimate path is a few hundred) records what its lanes were doing
-        // and leaves: the launch ends, the host reports MLRT_ERR_HIP (mlrt_context_check) instead of a wedged device.
-        if (MLRT_RARELY(++stall > P.stall_cap)) {
-            if (lane == 0) {
-                atomicAdd(&P.status[0], 1u);  // waves that gave up
-                P.status[1] = (unsigned int)blockIdx.x; P.status[2] = (unsigned int)wave;
-            }
-            P.status[4 + lane] = (unsigned int)phase | ((unsigned int)has_path << 8) | ((unsigned int)(c.node & 0xFFFF) << 16);  // (of the last such wave)
+        // The end of the loop, and watchdog (1).  No lane was traversing, parked for a batch or shading in this iteration:
+        // either every lane is idle - the wave is done - or the rest wait for an accumulator bank that only one of those could
+        // free, and nothing can ever change again (round 1 had such a slip in the lane state machine: it span forever and took
+        // the GPU with it).  Such a wave records what its lanes were doing and leaves: the launch ends and the host reports
+        // MLRT_ERR_HIP (mlrt_context_check) instead of a wedged device.  One scalar flag instead of the all-lanes-idle ballot
+        // that used to close every iteration.
+        if (MLRT_RARELY(nobody_runs)) {
+            if (__ballot(phase != PH_IDLE) != 0ull) MLRT_GIVE_UP();
             break;
         }
+#ifdef MLRT_DEBUG_BUILD
+        // Watchdog (2), debug build (build.py --debug) only: a countdown of iterations since a path of this wave last ended
+        // (KParams::stall_cap, default 2^24: seconds; a legitimate path takes a few hundred), reloaded from LDS when one does.
+        // Kept out of the release kernels: its scalar register and two instructions cost 1.5-2 % (C2 39.1 vs 38.5 ms).
+        if (MLRT_RARELY(--stall == 0u)) { MLRT_GIVE_UP(); break; }
+#endif
     }
     flush_finished_banks();  // (max_depth == 0 finishes its last samples inside the regeneration loop)
     if (MLRT_STATS_ON(P) && lane == 0) {

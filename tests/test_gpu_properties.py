@@ -312,21 +312,30 @@ def test_multi_device_frame_equals_the_single_context_frame(mlrt, earthmap, name
 
 
 def test_kernel_watchdog_ends_a_stalled_launch_with_an_error(mlrt):
-    """The persistent waves leave the kernel loop only when every lane is idle; a watchdog makes a wave that finishes no path
-    for stall_cap iterations give up, so a state-machine bug is an error message, not a wedged GPU.  Forced here with a cap
-    no real wave can meet (2 iterations); the default cap (2^24) never trips (every other test renders through it)."""
-    w = mlrt.World("random", 42)
-    cam = mlrt.default_camera(w, 1.5)
-    params = mlrt.make_params(w, 96, 64, 64)
-    for precision in (mlrt.PRECISION_FP32, mlrt.PRECISION_FP64):
-        r = mlrt.Renderer(w, cam, params, precision=precision, opts=mlrt.options(stall_cap=2))
-        with pytest.raises(mlrt.MlrtError) as e:
-            r.render()
-        assert e.value.code == mlrt.MLRT_ERR_HIP and "watchdog" in str(e.value) and "Lane phases" in str(e.value)
-        r.close()
-        good = mlrt.Renderer(w, cam, params, precision=precision)
-        img = good.render()
-        good.check()
-        assert img.any()
-        good.close()
-    w.close()
+    """The persistent waves leave the kernel loop only when every lane is idle.  Every build gives up when no lane can make
+    progress any more; the debug build (build.py --debug) additionally counts iterations since a path of the wave last ended
+    (mlrt_options.stall_cap), so that a state-machine bug is an error message, not a wedged GPU.  Forced here in the debug
+    library with a cap no real wave can meet (2 iterations); the same library with the default cap renders the frame."""
+    import sys
+    debug_lib = os.path.join(os.path.dirname(mlrt.LIB_PATH), "libmlrt_hip_debug.so")
+    if not os.path.exists(debug_lib):
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(mlrt.LIB_PATH)), "build.py"), "--debug"], check=True, capture_output=True)
+    script = (
+        "import importlib, sys\n"
+        "import torch\n"
+        "sys.path.insert(0, %r)\n"
+        "m = importlib.import_module('mu-lambda-raytracer_amd')\n"
+        "w = m.World('random', 42); cam = m.default_camera(w, 1.5); p = m.make_params(w, 96, 64, 64)\n"
+        "for prec in (m.PRECISION_FP32, m.PRECISION_FP64):\n"
+        "    r = m.Renderer(w, cam, p, precision=prec, opts=m.options(stall_cap=2))\n"
+        "    try:\n"
+        "        r.render(); print('NO ERROR')\n"
+        "    except m.MlrtError as e:\n"
+        "        print('ERR', e.code, 'watchdog' in str(e), 'Lane phases' in str(e))\n"
+        "    r.close()\n"
+        "    g = m.Renderer(w, cam, p, precision=prec); img = g.render(); g.check(); print('OK', bool(img.any())); g.close()\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLRT_LIB=debug_lib)
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=120)
+    lines = [ln for ln in out.stdout.split("\n") if ln.startswith(("ERR", "OK", "NO"))]
+    assert lines == ["ERR %d True True" % mlrt.MLRT_ERR_HIP, "OK True"] * 2, (out.stdout, out.stderr[-1500:])
