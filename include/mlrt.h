@@ -88,7 +88,10 @@ typedef struct mlrt_sphere {  /* shapes.rs:25-42 */
     int32_t _pad;
 } mlrt_sphere;
 
-typedef struct mlrt_box {  /* shapes.rs:166-198 Block: six AARects sharing one material */
+typedef struct mlrt_box {  /* shapes.rs:166-198 Block: six AARects sharing one material.  min <= max componentwise (the
+                            * reference's Block::new(p0, p1) with reversed corners yields degenerate sides, aarects.rs:39: rejected).
+                            * Hits carry u = v = 0: a material whose texture chain samples an image (which reads u, v) on a
+                            * box renders texel (0, last row) everywhere. */
     double min[3], max[3];
     int32_t material;
     int32_t _pad;

@@ -59,7 +59,7 @@ UNITS = [
     # strict build (test instrument): additionally the reference's BVH topology and slab arithmetic
     ("kernel_f64s.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256",
                                "-DMLRT_LEAN_WAVES_PER_EU=1", "-DMLRT_FULL_WAVES_PER_EU=1", "-ffp-contract=off"] + DEBUG_FLAGS),
-    ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"]),
+    ("api.o", os.path.join(HERE, "csrc", "mlrt_api.cpp"), ["-ffp-contract=off"] + DEBUG_FLAGS),
     ("multi.o", os.path.join(HERE, "csrc", "mlrt_multi.cpp"), []),
     ("multi_kernels.o", os.path.join(HERE, "csrc", "mlrt_multi_kernels.hip"), ["--offload-arch=" + ARCH]),
     ("host_api.o", os.path.join(HERE, "host", "host_api.cpp"), ["-ffp-contract=off"]),

@@ -30,6 +30,14 @@ MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
 MLRT_DECLARE_BUILD(f64s)
 MLRT_DECLARE_BUILD(f64c)
+#ifdef MLRT_DEBUG_BUILD
+#define MLRT_DECLARE_PROBE(sfx) \
+    int mlrt_probe_launch_##sfx(int kind, const void* kparams, int n, const void* a, const void* b, void* c, void* d2, int iarg, hipStream_t stream);
+MLRT_DECLARE_PROBE(f32)
+MLRT_DECLARE_PROBE(f64)
+MLRT_DECLARE_PROBE(f64s)
+MLRT_DECLARE_PROBE(f64c)
+#endif
 }
 
 namespace mlrt {
@@ -46,8 +54,14 @@ struct KernelBuild {
     int (*acc_bytes_per_wave)(void);
     int (*lds_frame_bytes)(void);
     int (*occupancy)(int, int, size_t);
+    int (*probe)(int, const void*, int, const void*, const void*, void*, void*, int, hipStream_t);  // debug library only, else nullptr
 };
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx}
+#ifdef MLRT_DEBUG_BUILD
+#define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
+#else
+#define MLRT_PROBE_OF(sfx) nullptr
+#endif
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx)}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -66,7 +80,13 @@ void validate(const mlrt_scene& s) {
                  "negative element count");
     auto mat_ok = [&](int32_t m) { return m >= 0 && m < s.n_materials; };
     for (int i = 0; i < s.n_spheres; i++) MLRT_REQUIRE(mat_ok(s.spheres[i].material), "sphere material out of range");
-    for (int i = 0; i < s.n_boxes; i++) MLRT_REQUIRE(mat_ok(s.boxes[i].material), "box material out of range");
+    for (int i = 0; i < s.n_boxes; i++) {
+        MLRT_REQUIRE(mat_ok(s.boxes[i].material), "box material out of range");
+        // Block::new(p0, p1) with a corner pair that is not (min, max) builds degenerate rects in the reference (AARect::new keeps
+        // a1_v0 as given, aarects.rs:39 - quirk Q2 - so a side can come out with a1_v0 > a1_v1 and never be hit): not a shape
+        // anyone means, and not what the device's slab form of a Block would render
+        for (int k = 0; k < 3; k++) MLRT_REQUIRE(s.boxes[i].min[k] <= s.boxes[i].max[k], "box min must not exceed max (Block::new with reversed corners is degenerate in the reference)");
+    }
     for (int i = 0; i < s.n_rects; i++) {
         const mlrt_rect& r = s.rects[i];
         MLRT_REQUIRE(mat_ok(r.material), "rect material out of range");
@@ -1036,4 +1056,157 @@ int32_t mlrt_render(const mlrt_scene* scene, const mlrt_camera* camera, const ml
     return rc;
 }
 
+}  // extern "C"
+
+// ---- directed probes (debug library only; see "directed probes" in mlrt_kernel.hip and tests/test_gpu_directed.py) ----------
+namespace {
+struct DeviceBuffers {  // scratch for one probe call
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() { for (void* p : ptrs) (void)hipFree(p); }
+    void* alloc(size_t bytes, const void* host = nullptr) {
+        void* p = nullptr;
+        MLRT_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        ptrs.push_back(p);
+        if (host && bytes) MLRT_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        return p;
+    }
+};
+template <typename R>
+void scene_params(const mlrt_context* c, uint64_t seed, KParams<R>& K) {
+    K.blob = c->d_blob; K.blob_bytes = c->blob_bytes;
+    K.off_nodes = c->off[0]; K.off_materials = c->off[1]; K.off_textures = c->off[2];
+    K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
+    K.off_sphere_index = c->off[5]; K.n_sphere_index = c->n_sphere_index;
+    K.n_nodes = c->n_nodes;
+    K.images = c->d_images;
+    K.seed_lo = (uint32_t)seed; K.seed_hi = (uint32_t)(seed >> 32);
+}
+// kind, and the launch on the context's build; `with` fills the KParams of the right type
+template <typename F>
+void probe_launch(mlrt_context* c, int kind, uint64_t seed, int n, const void* a, const void* b, void* out, void* out2, int iarg, F&& with) {
+    if (!c->build->probe) throw Fail{MLRT_ERR_UNSUPPORTED, "the directed probes exist in the debug build of the library only (build.py --debug)"};
+    MLRT_REQUIRE(c->variant == 0, "probes need the FULL packing of the scene: create the context with options.force_full = 1");
+    MLRT_HIP(hipSetDevice(c->device));
+    int rc;
+    if (c->precision == MLRT_PRECISION_FP32) {
+        KParams<float> K{};
+        scene_params(c, seed, K);
+        with(K);
+        rc = c->build->probe(kind, &K, n, a, b, out, out2, iarg, nullptr);
+    } else {
+        KParams<double> K{};
+        scene_params(c, seed, K);
+        with(K);
+        rc = c->build->probe(kind, &K, n, a, b, out, out2, iarg, nullptr);
+    }
+    if (rc != 0) throw Fail{MLRT_ERR_HIP, std::string("probe launch failed: ") + hipGetErrorString((hipError_t)rc)};
+    MLRT_HIP(hipDeviceSynchronize());
+}
+}  // namespace
+
+extern "C" {
+// One bounce of each ray through the context's packed scene: out[n][24] = hit, t, p xyz, normal xyz, u, v, front_face, scattered,
+// scattered origin xyz, scattered direction xyz, attenuation (scattered) | emitted (not) rgb, stream draw index after the
+// traversal, material kind, entry index.  psd[n][3] = Philox (pixel, sample, draw index) the ray starts with.
+int32_t mlrt_debug_probe_rays(mlrt_context* ctx, uint64_t seed, int32_t n, const double* rays, const uint32_t* psd, double* out) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && rays && psd && out && n >= 0, "bad argument");
+        DeviceBuffers d;
+        void* d_rays = d.alloc((size_t)n * 6 * sizeof(double), rays);
+        void* d_psd = d.alloc((size_t)n * 3 * sizeof(uint32_t), psd);
+        void* d_out = d.alloc((size_t)n * 24 * sizeof(double));
+        probe_launch(ctx, 0, seed, n, d_rays, d_psd, d_out, nullptr, 0, [](auto&) {});
+        MLRT_HIP(hipMemcpy(out, d_out, (size_t)n * 24 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+// Camera::get_ray for (i, j, sample) triples of a frame: out[n][6] = origin, direction
+int32_t mlrt_debug_probe_camera(mlrt_context* ctx, const mlrt_camera* cam, const mlrt_params* p, int32_t n, const int32_t* ijs, double* out) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && cam && p && ijs && out && n >= 0, "bad argument");
+        DeviceBuffers d;
+        void* d_ijs = d.alloc((size_t)n * 3 * sizeof(int32_t), ijs);
+        void* d_out = d.alloc((size_t)n * 6 * sizeof(double));
+        probe_launch(ctx, 1, p->seed, n, d_ijs, nullptr, d_out, nullptr, 0, [&](auto& K) {
+            for (int k = 0; k < 3; k++) {
+                K.cam_origin[k] = cam->origin[k]; K.cam_llc[k] = cam->lower_left_corner[k];
+                K.cam_horizontal[k] = cam->horizontal[k]; K.cam_vertical[k] = cam->vertical[k];
+                K.cam_u[k] = cam->u[k]; K.cam_v[k] = cam->v[k];
+            }
+            K.lens_radius = cam->lens_radius; K.has_lens = cam->lens_radius != 0.0 ? 1 : 0;
+            K.inv_wm1 = 1.0 / ((double)p->image_width - 1.0); K.inv_hm1 = 1.0 / ((double)p->image_height - 1.0);
+            K.width = p->image_width; K.height = p->image_height;
+        });
+        MLRT_HIP(hipMemcpy(out, d_out, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+// The build's culling test on explicit boxes (entries made by the packer's rounding rule for this build) and rays, t in [0.001, tmax]
+int32_t mlrt_debug_probe_slab(mlrt_context* ctx, int32_t n, const double* boxes, const double* rays, const double* tmax, int32_t* hit) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && boxes && rays && tmax && hit && n >= 0, "bad argument");
+        if (!ctx->build->probe) throw Fail{MLRT_ERR_UNSUPPORTED, "the directed probes exist in the debug build of the library only (build.py --debug)"};
+        MLRT_HIP(hipSetDevice(ctx->device));
+        DeviceBuffers d;
+        const bool cull32 = ctx->precision == MLRT_PRECISION_FP32 || (ctx->precision == MLRT_PRECISION_FP64 && !ctx->opt.cull_f64);
+        const Round round = ctx->precision == MLRT_PRECISION_FP64_STRICT ? Round::EXACT : (ctx->precision == MLRT_PRECISION_FP64 && cull32 ? Round::RIGOROUS : Round::OUTWARD);
+        void* d_boxes;
+        auto bounds_of = [&](int i) { Bounds b; for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(boxes[i * 6 + k], boxes[i * 6 + 3 + k]); b.hi[k] = std::fmax(boxes[i * 6 + k], boxes[i * 6 + 3 + k]); } return b; };
+        if (cull32) {
+            Entries<float> E; E.round = round;
+            std::vector<DNode<float>> e((size_t)n);
+            for (int i = 0; i < n; i++) e[(size_t)i] = E.box_entry(bounds_of(i), 0);
+            d_boxes = d.alloc(e.size() * sizeof(DNode<float>), e.data());
+        } else {
+            Entries<double> E; E.round = round;
+            std::vector<DNode<double>> e((size_t)n);
+            for (int i = 0; i < n; i++) {
+                e[(size_t)i] = E.box_entry(bounds_of(i), 0);
+                if (round == Round::EXACT) for (int k = 0; k < 6; k++) e[(size_t)i].v[k] = boxes[i * 6 + k];  // (the reference's AABB as given, min/max not sorted)
+            }
+            d_boxes = d.alloc(e.size() * sizeof(DNode<double>), e.data());
+        }
+        void* d_rays = d.alloc((size_t)n * 6 * sizeof(double), rays);
+        void* d_tmax = d.alloc((size_t)n * sizeof(double), tmax);
+        void* d_hit = d.alloc((size_t)n * sizeof(int32_t));
+        const int rc = ctx->build->probe(2, d_boxes, n, d_rays, d_tmax, d_hit, nullptr, 0, nullptr);
+        if (rc != 0) throw Fail{MLRT_ERR_HIP, std::string("probe launch failed: ") + hipGetErrorString((hipError_t)rc)};
+        MLRT_HIP(hipDeviceSynchronize());
+        MLRT_HIP(hipMemcpy(hit, d_hit, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    });
+}
+// Perlin::turbulence of table `table` at points (already multiplied by the texture's scale): serial evaluation and the wave-level one
+int32_t mlrt_debug_probe_turbulence(mlrt_context* ctx, int32_t table, int32_t n, const double* points, double* serial, double* wave) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && points && serial && wave && n >= 0 && table >= 0, "bad argument");
+        DeviceBuffers d;
+        void* d_p = d.alloc((size_t)n * 3 * sizeof(double), points);
+        void* d_s = d.alloc((size_t)n * sizeof(double));
+        void* d_w = d.alloc((size_t)n * sizeof(double));
+        probe_launch(ctx, 3, 0, n, d_p, nullptr, d_s, d_w, table, [](auto&) {});
+        MLRT_HIP(hipMemcpy(serial, d_s, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        MLRT_HIP(hipMemcpy(wave, d_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+// Texture::value of texture `tex` at uvp[n][5] = u, v, p xyz: out[n][3]
+int32_t mlrt_debug_probe_texture(mlrt_context* ctx, int32_t tex, int32_t n, const double* uvp, double* out) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && uvp && out && n >= 0 && tex >= 0, "bad argument");
+        DeviceBuffers d;
+        void* d_in = d.alloc((size_t)n * 5 * sizeof(double), uvp);
+        void* d_out = d.alloc((size_t)n * 3 * sizeof(double));
+        probe_launch(ctx, 4, 0, n, d_in, nullptr, d_out, nullptr, tex, [](auto&) {});
+        MLRT_HIP(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+// One finished sample of radiance[i] accumulated (to_fixed) and resolved with spp (to_rgb): rgb[n]
+int32_t mlrt_debug_probe_to_rgb(mlrt_context* ctx, int32_t spp, int32_t n, const double* radiance, int32_t* rgb) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && radiance && rgb && n >= 0 && spp >= 1, "bad argument");
+        DeviceBuffers d;
+        void* d_in = d.alloc((size_t)n * sizeof(double), radiance);
+        void* d_rgb = d.alloc((size_t)n * sizeof(int32_t));
+        void* d_acc = d.alloc((size_t)n * sizeof(unsigned long long));
+        probe_launch(ctx, 5, 0, n, d_in, ctx->d_tile_counter, d_rgb, d_acc, spp, [](auto&) {});
+        MLRT_HIP(hipMemcpy(rgb, d_rgb, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    });
+}
 }  // extern "C"

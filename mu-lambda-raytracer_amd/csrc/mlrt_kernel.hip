@@ -1580,6 +1580,153 @@ __global__ void mlrt_resolve_kernel(unsigned long long* acc, int n, int spp, int
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- directed probes (debug build)
+// Test instruments (build.py --debug only; exported through mlrt_debug_probe_* in mlrt_api.cpp): the device functions above
+// evaluated on CHOSEN inputs - one thread per input, a plain per-thread loop - so that tests/test_gpu_directed.py can compare
+// each of them with the oracle on the edge cases an image almost never produces (axis-parallel rays, origins inside boxes,
+// tangent spheres, closed rect edges, media entered from inside, total internal reflection, NaN sums ...).  The probes walk
+// the REAL packed scene of a context with the REAL step arithmetic; only the lane scheduling of the megakernel (phases,
+// batches) is replaced by a loop.
+#ifdef MLRT_DEBUG_BUILD
+constexpr int kProbeRayOut = 24;  // doubles per ray, see mlrt_debug_probe_rays
+template <uint32_t FEAT>
+__global__ void mlrt_probe_rays_kernel(const KParams<real> P, int n, const double* rays, const uint32_t* psd, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Scene S;
+    S.nodes = reinterpret_cast<const DNode<creal>*>(P.blob + P.off_nodes);
+    S.materials = reinterpret_cast<const DMaterial<real>*>(P.blob + P.off_materials);
+    S.textures = reinterpret_cast<const DTexture<real>*>(P.blob + P.off_textures);
+    S.perlin_vec = reinterpret_cast<const real*>(P.blob + P.off_perlin_vec);
+    S.perlin_perm = reinterpret_cast<const uint16_t*>(P.blob + P.off_perlin_perm);
+    S.images = P.images;
+    const RngKey key = {P.seed_lo, P.seed_hi};
+    P3 o = mkp(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]), d = mkp(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    Rng g = {psd[i * 3 + 0], psd[i * 3 + 1], psd[i * 3 + 2], 0u};
+    if ((g.draw & 3u) == 3u) {  // (word 3 of the current block is lane state in the kernel)
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10(key.k0, key.k1, g.draw >> 2, g.sample, g.pixel, 0u, w0, w1, w2, w3);
+        g.b3 = w3;
+    }
+    Cursor c;
+    c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+    Ray wr;
+    wr.o = o; wr.d = d;
+    c.sr = slab_ray(wr);
+    long steps = 0;
+    for (;;) {  // the megakernel's step, one lane, no phases
+        const DNode<creal> e = S.nodes[c.node];
+        const int kind = e.tag & TAG_KIND_MASK;
+        if (kind == TAG_END || ++steps > 1000000) break;
+        const creal far_bound = slab_far_bound(c.closest);
+        if (kind == TAG_INNER) { c.node = slab_hit_any(e, c.sr, far_bound) ? c.node + 1 : e.link; continue; }
+        if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
+            if (kProduct64) {
+                if (!slab_hit_any(e, c.sr, far_bound)) { c.node += slots_of(e.tag); continue; }
+            } else {
+                double t; int aux = 0;
+                bool hit_box;
+                if (kFast) hit_box = box_hit_fast(e, c.sr, 0.001, c.closest, t, aux);
+                else {
+                    const double b[6] = {(double)e.v[0], (double)e.v[1], (double)e.v[2], (double)e.v[3], (double)e.v[4], (double)e.v[5]};
+                    hit_box = box_hit_exact(b, mkp((double)c.sr.ofx, (double)c.sr.ofy, (double)c.sr.ofz), mkp((double)c.sr.ix, (double)c.sr.iy, (double)c.sr.iz), 0.001, c.closest, t, aux);
+                }
+                if (hit_box) { c.closest = t; c.hit_node = c.node; c.hit_aux = aux; c.hit_xf = c.xf; }
+                c.node += 1;
+                continue;
+            }
+        }
+        special_entry<FEAT>(S, e, c, o, d, g, key);
+    }
+    double* r = out + (size_t)i * kProbeRayOut;
+    for (int k = 0; k < kProbeRayOut; k++) r[k] = 0.0;
+    r[21] = (double)g.draw;  // draws consumed by the traversal (media)
+    if (c.hit_node < 0) return;
+    const HitAttr h = hit_attributes<FEAT>(S, c, o, d);
+    r[0] = 1.0; r[1] = c.closest; r[2] = h.p.x; r[3] = h.p.y; r[4] = h.p.z;
+    r[5] = (double)h.normal.x; r[6] = (double)h.normal.y; r[7] = (double)h.normal.z;
+    r[8] = (double)h.u; r[9] = (double)h.v; r[10] = h.front_face ? 1.0 : 0.0;
+    V3 thr = mk(1, 1, 1), emitted = mk(0, 0, 0);
+    const int bounce = (int)((g.draw + 3u) >> 2) - 1;  // (the block rule of scenes without media: block = 1 + bounce)
+    const bool scattered = scatter<FEAT>(S, h, o, d, thr, emitted, g, key, bounce, false, (real)0);
+    r[11] = scattered ? 1.0 : 0.0;
+    if (scattered) {
+        r[12] = o.x; r[13] = o.y; r[14] = o.z; r[15] = d.x; r[16] = d.y; r[17] = d.z;
+        r[18] = (double)thr.x; r[19] = (double)thr.y; r[20] = (double)thr.z;
+    } else {
+        r[18] = (double)emitted.x; r[19] = (double)emitted.y; r[20] = (double)emitted.z;
+    }
+    r[22] = (double)(S.materials[S.nodes[c.hit_node].link].kind & 0xFF);
+    r[23] = (double)c.hit_node;
+}
+// Camera::get_ray through gen_camera_ray: pixel (i, j) of a W x H frame, sample `smp` -> origin, direction
+__global__ void mlrt_probe_camera_kernel(const KParams<real> P, int n, const int32_t* ijs, double* out) {
+    __shared__ FrameParams F;
+    if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];
+    if (threadIdx.x < 3) {
+        F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x];
+        F.through0[threadIdx.x] = (float)(P.cam_llc[threadIdx.x] - P.cam_origin[threadIdx.x]);
+        F.hor_f[threadIdx.x] = (float)P.cam_horizontal[threadIdx.x]; F.ver_f[threadIdx.x] = (float)P.cam_vertical[threadIdx.x];
+        F.u_f[threadIdx.x] = (float)P.cam_u[threadIdx.x]; F.v_f[threadIdx.x] = (float)P.cam_v[threadIdx.x];
+    }
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RngKey key = {P.seed_lo, P.seed_hi};
+    const int i = ijs[k * 3 + 0], j = ijs[k * 3 + 1];
+    Rng g = {(uint32_t)(j * P.width + i), (uint32_t)ijs[k * 3 + 2], 0u, 0u};
+    P3 o, d;
+    gen_camera_ray(P, F, g, key, i, j, o, d);
+    double* r = out + (size_t)k * 6;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+// the build's culling test (slab_hit_any over an entry made by the packer's rounding rule) on explicit boxes and rays
+__global__ void mlrt_probe_slab_kernel(int n, const DNode<creal>* boxes, const double* rays, const double* tmax, int32_t* hit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = mkp(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]); r.d = mkp(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    r.a = 0.0; r.inv_a = 0.0;
+    hit[i] = slab_hit_any(boxes[i], slab_ray(r), slab_far_bound(tmax[i])) ? 1 : 0;
+}
+// Perlin::turbulence (textures.rs:76-88) at scale * p: the serial evaluation, and - fast build - the wave-level one of the
+// shading batch (one point per wave: 64 threads per point)
+__global__ void mlrt_probe_turbulence_kernel(const KParams<real> P, int table, int n, const double* points, double* serial, double* wave) {
+    Scene S;
+    S.nodes = nullptr; S.materials = nullptr; S.textures = nullptr; S.images = nullptr;
+    S.perlin_vec = reinterpret_cast<const real*>(P.blob + P.off_perlin_vec);
+    S.perlin_perm = reinterpret_cast<const uint16_t*>(P.blob + P.off_perlin_perm);
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    const V3 p = mk((real)points[k * 3 + 0], (real)points[k * 3 + 1], (real)points[k * 3 + 2]);
+    if (lane == 0) serial[k] = (double)perlin_turbulence(S, table, p);
+    const float w = wave_turbulence(S, table, (float)p.x, (float)p.y, (float)p.z, lane);
+    if (lane == 0) wave[k] = (double)w;
+}
+// Texture::value (textures.rs, image_texture.rs) of texture `tex` at (u, v, p)
+__global__ void mlrt_probe_texture_kernel(const KParams<real> P, int tex, int n, const double* uvp, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Scene S;
+    S.nodes = nullptr;
+    S.materials = reinterpret_cast<const DMaterial<real>*>(P.blob + P.off_materials);
+    S.textures = reinterpret_cast<const DTexture<real>*>(P.blob + P.off_textures);
+    S.perlin_vec = reinterpret_cast<const real*>(P.blob + P.off_perlin_vec);
+    S.perlin_perm = reinterpret_cast<const uint16_t*>(P.blob + P.off_perlin_perm);
+    S.images = P.images;
+    const V3 c = texture_value<FEAT_ALL>(S, tex, mk(0, 0, 0), (real)uvp[i * 5 + 0], (real)uvp[i * 5 + 1], mk((real)uvp[i * 5 + 2], (real)uvp[i * 5 + 3], (real)uvp[i * 5 + 4]));
+    out[i * 3 + 0] = (double)c.x; out[i * 3 + 1] = (double)c.y; out[i * 3 + 2] = (double)c.z;
+}
+// to_fixed (the kernel's accumulation of one finished sample) followed by the resolve kernel's to_rgb, on explicit radiance values
+__global__ void mlrt_probe_accumulate_kernel(int n, const double* radiance, unsigned long long* acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    acc[i] = to_fixed((real)radiance[i]);
+}
+#endif  // MLRT_DEBUG_BUILD
+
 }  // namespace MLRT_NS
 
 // ---------------------------------------------------------------------------------------------- launcher
@@ -1644,3 +1791,26 @@ extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene
     if (variant == 1) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds);
     return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds);
 }
+
+#ifdef MLRT_DEBUG_BUILD
+// Probe launchers (see "directed probes" above).  `kind`: 0 rays, 1 camera, 2 slab, 3 turbulence, 4 texture, 5 accumulate + resolve.
+// All pointers are device pointers; returns a hipError_t.
+extern "C" int MLRT_CAT(mlrt_probe_launch_, MLRT_SUFFIX)(int kind, const void* kparams, int n, const void* a, const void* b, void* c, void* d2, int iarg,
+                                                          hipStream_t stream) {
+    using namespace MLRT_NS;
+    const mlrt::KParams<real>& P = *static_cast<const mlrt::KParams<real>*>(kparams);
+    const unsigned grid = (unsigned)((n + 63) / 64);
+    if (n <= 0) return 0;
+    if (kind == 0) hipLaunchKernelGGL((mlrt_probe_rays_kernel<mlrt::FEAT_ALL>), dim3(grid), dim3(64), 0, stream, P, n, static_cast<const double*>(a), static_cast<const uint32_t*>(b), static_cast<double*>(c));
+    else if (kind == 1) hipLaunchKernelGGL(mlrt_probe_camera_kernel, dim3(grid), dim3(64), 0, stream, P, n, static_cast<const int32_t*>(a), static_cast<double*>(c));
+    else if (kind == 2) hipLaunchKernelGGL(mlrt_probe_slab_kernel, dim3(grid), dim3(64), 0, stream, n, static_cast<const mlrt::DNode<creal>*>(kparams), static_cast<const double*>(a), static_cast<const double*>(b), static_cast<int32_t*>(c));
+    else if (kind == 3) hipLaunchKernelGGL(mlrt_probe_turbulence_kernel, dim3((unsigned)n), dim3(64), 0, stream, P, iarg, n, static_cast<const double*>(a), static_cast<double*>(c), static_cast<double*>(d2));
+    else if (kind == 4) hipLaunchKernelGGL(mlrt_probe_texture_kernel, dim3(grid), dim3(64), 0, stream, P, iarg, n, static_cast<const double*>(a), static_cast<double*>(c));
+    else if (kind == 5) {
+        hipLaunchKernelGGL(mlrt_probe_accumulate_kernel, dim3(grid), dim3(64), 0, stream, n, static_cast<const double*>(a), static_cast<unsigned long long*>(d2));
+        hipLaunchKernelGGL(mlrt_resolve_kernel, dim3(grid), dim3(64), 0, stream, static_cast<unsigned long long*>(d2), n, iarg, static_cast<int32_t*>(c), static_cast<double*>(nullptr), static_cast<unsigned int*>(const_cast<void*>(b)));
+    } else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+extern "C" int MLRT_CAT(mlrt_probe_entry_bytes_, MLRT_SUFFIX)(void) { return (int)sizeof(mlrt::DNode<MLRT_NS::creal>); }
+#endif

@@ -301,6 +301,7 @@ struct Perlin {  // textures.rs:51-149
     Vec3 ranvec[POINT_COUNT];
     uint64_t perm_x[POINT_COUNT], perm_y[POINT_COUNT], perm_z[POINT_COUNT];
     int turbulence_depth;
+    Perlin() : turbulence_depth(7) {}  // tables filled in by the caller (oracle_scene.cpp: a scene that carries its tables)
     explicit Perlin(Rng& rng) {  // textures.rs:62-74
         for (int i = 0; i < POINT_COUNT; i++) ranvec[i] = vec3_random(-1.0, 1.0, rng).unit();
         permute(rng, perm_x);
@@ -365,6 +366,7 @@ struct NoiseTexture : Texture {  // textures.rs:151-167
     std::shared_ptr<Perlin> noise;
     double scale;
     NoiseTexture(double s, Rng& rng) : noise(std::make_shared<Perlin>(rng)), scale(s) {}
+    NoiseTexture(std::shared_ptr<Perlin> tables, double s) : noise(tables), scale(s) {}
     Color value(double, double, const Point3& p) const override {
         // Color::ONE * 0.5 * (1.0 + sin(scale*p.z + 10*turb(scale*p)))  (left-assoc: (ONE*0.5)*x)
         double x = 1.0 + std::sin(scale * p.z() + 10.0 * noise->turbulence(scale * p));

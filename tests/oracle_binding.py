@@ -14,7 +14,7 @@ STAT_NAMES = ["samples", "rays", "aabb_tests", "sphere_tests", "rect_tests", "sc
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "oracle_core.hpp", "oracle_main.cpp", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "oracle_scene.cpp", "oracle_core.hpp", "oracle_main.cpp", "Makefile")]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B" if force else "-s", "all"])
@@ -89,6 +89,40 @@ class OracleWorld:
             self.handle = None
 
 
+class OracleScene:
+    """The oracle over an arbitrary flattened scene (oracle/oracle_scene.cpp): per-call probes for the directed tests."""
+
+    def __init__(self, oracle, scene_struct):
+        self.L = oracle.L
+        self.scene = scene_struct  # (keeps the arrays alive)
+        self.handle = self.L.orc_scene_new(C.byref(scene_struct))
+        if not self.handle:
+            raise RuntimeError("oracle cannot build the scene")
+
+    def probe_rays(self, seed, rays, psd):
+        rays = np.ascontiguousarray(rays, dtype=np.float64); psd = np.ascontiguousarray(psd, dtype=np.uint32)
+        out = np.zeros((len(rays), 24))
+        self.L.orc_scene_probe_rays(self.handle, C.c_uint64(seed), len(rays), rays.ctypes.data_as(C.c_void_p), psd.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def texture_value(self, tex, uvp):
+        uvp = np.ascontiguousarray(uvp, dtype=np.float64)
+        out = np.zeros((len(uvp), 3))
+        self.L.orc_scene_texture_value(self.handle, int(tex), len(uvp), uvp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def turbulence(self, table, points):
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        out = np.zeros(len(points))
+        self.L.orc_scene_turbulence(self.handle, int(table), len(points), points.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.L.orc_scene_free(self.handle)
+            self.handle = None
+
+
 class Oracle:
     def __init__(self):
         build_oracle()
@@ -116,7 +150,30 @@ class Oracle:
         L.orc_to_rgb.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32)]
         L.orc_sphere_hit.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.orc_world_name.restype = C.c_char_p
+        L.orc_scene_new.restype = C.c_void_p
+        L.orc_scene_new.argtypes = [C.c_void_p]
+        L.orc_scene_free.argtypes = [C.c_void_p]
+        L.orc_scene_probe_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scene_texture_value.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_scene_turbulence.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_probe_get_ray.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_probe_to_rgb.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         self.L = L
+
+    def scene(self, scene_struct):
+        return OracleScene(self, scene_struct)
+
+    def get_rays(self, camera19, width, height, seed, ijs):
+        ijs = np.ascontiguousarray(ijs, dtype=np.int32)
+        out = np.zeros((len(ijs), 6))
+        self.L.orc_probe_get_ray((C.c_double * 19)(*camera19), width, height, C.c_uint64(seed), len(ijs), ijs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def to_rgb_array(self, spp, sums):
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        out = np.zeros(len(sums), dtype=np.int32)
+        self.L.orc_probe_to_rgb(spp, len(sums), sums.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def world_names(self):
         return [self.L.orc_world_name(i).decode() for i in range(self.L.orc_world_count())]
