@@ -5,6 +5,7 @@ image level (oracle in device-contract mode vs oracle in the reference's own PCG
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from oracle_binding import RNG_PCG_ROW, RNG_PHILOX_SAMPLE
 
@@ -58,12 +59,18 @@ def test_closed_form_uses_exactly_three_and_two_draws(oracle):
     assert abs(np.arctan2(p[1], p[0]) % (2 * np.pi) - 2 * np.pi * u[1]) < 1e-12
 
 
-def test_device_contract_renders_the_same_picture_as_the_reference_algorithm(oracle):
-    """oracle[Philox streams + inverse-CDF samplers] vs oracle[the reference's PCG64 row streams + rejection loops]:
-    8x8 block means of the linear radiance must agree as well as two PCG renders with different render seeds do."""
-    w = oracle.world("random", 42)
-    cam = oracle.camera_new((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
-    W, H, spp = 144, 96, 96
+@pytest.mark.parametrize("name,aspect,width,height,spp,lens", [("random", 1.5, 144, 96, 96, True), ("cornell_smoke", 1.0, 96, 96, 192, False),
+                                                              ("final_scene", 1.0, 96, 96, 128, False)])
+def test_device_contract_renders_the_same_picture_as_the_reference_algorithm(oracle, earthmap, name, aspect, width, height, spp, lens):
+    """oracle[Philox streams + inverse-CDF samplers + one block per scatter] vs oracle[the reference's PCG64 row streams + rejection
+    loops]: 8x8 block means of the linear radiance must agree as well as two PCG renders with different render seeds do.  `random`
+    with a lens covers the disk sampler; cornell_smoke and final_scene cover the MEDIUM draws (volumes.rs:47), which the
+    block-per-scatter rule of the device contract moves to other words of the stream (oracle_core.hpp begin_scatter / end_scatter)."""
+    w = oracle.world(name, 42, earthmap if name == "final_scene" else None)
+    lookfrom, lookat, fov = w.camera()
+    focus = 10.0 if lens else float(np.linalg.norm(np.array(lookat) - np.array(lookfrom)))
+    cam = oracle.camera_new(lookfrom, lookat, (0, 1, 0), fov, aspect, 0.1 if lens else 0.0, focus)
+    W, H = width, height
 
     def blocks(mode, seed):
         _, acc, _, _ = w.render(cam, W, H, spp, seed=seed, rng_mode=mode, want_accum=True)
@@ -73,6 +80,6 @@ def test_device_contract_renders_the_same_picture_as_the_reference_algorithm(ora
     pcg_a, pcg_b, dev = blocks(RNG_PCG_ROW, 1), blocks(RNG_PCG_ROW, 2), blocks(RNG_PHILOX_SAMPLE, 1)
     noise = np.sqrt(np.mean((pcg_a - pcg_b) ** 2))
     diff = np.sqrt(np.mean((dev - pcg_a) ** 2))
-    assert diff < 1.35 * noise, (diff, noise)
-    assert abs(dev.mean() / pcg_a.mean() - 1.0) < 0.01
+    assert diff < 1.35 * noise, (name, diff, noise)
+    assert abs(dev.mean() / pcg_a.mean() - 1.0) < (0.01 if name == "random" else 0.03), (name, dev.mean() / pcg_a.mean())
     w.close()
