@@ -12,7 +12,8 @@ def probe(name, W, aspect, spp, ranks=(1, 2, 4, 8), steps=5):
     earth = pkg.load_earthmap() if name in ("earth", "final_scene") else None
     w = pkg.World(name, 42, earth)
     H = pkg.image_height(W, aspect)
-    r = pkg.Renderer(w, pkg.default_camera(w, aspect), pkg.make_params(w, W, H, spp))
+    prec = int(os.environ.get('MLRT_PREC', '0'))
+    r = pkg.Renderer(w, pkg.default_camera(w, aspect), pkg.make_params(w, W, H, spp), precision=prec)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream(dev)
     base = None
@@ -29,7 +30,7 @@ def probe(name, W, aspect, spp, ranks=(1, 2, 4, 8), steps=5):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         base = base or ms
-        print("%s %dx%d spp %d: 1/%d of the rows: %.2f ms/step (kernel %.2f ms) -> speedup over N=1 %.2fx (ideal %d)" % (name, W, H, spp, n, ms, r.last_kernel_ms(), base / ms, n), flush=True)
+        print("prec %d %s %dx%d spp %d: 1/%d of the rows: %.2f ms/step (kernel %.2f ms) -> speedup over N=1 %.2fx (ideal %d)" % (prec, name, W, H, spp, n, ms, r.last_kernel_ms(), base / ms, n), flush=True)
     r.close(); w.close()
 
 if __name__ == "__main__":

@@ -1,23 +1,18 @@
-# Round profile: kernel-trace stats + HBM traffic counters (separate passes, as the microarch guide prescribes) for one bench run.
+# Round profile: bench line, kernel-trace stats of the same command, PMC summaries (tools/gpu_pmc.sh) for the headline config in
+# both precisions and for the FULL variant (c4), the VALU issue microbenchmark, the strong-scaling probe.
+# usage: bash tools/gpu_profile_round.sh [tag]       outputs under gpurun_out/<tag>_*
 export TMPDIR=/tmp
-R=${1:-r01}
-O=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
-python bench.py --steps 3 --warmup 1 > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; cat gpurun_out/bench_$R.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o $R -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$R.trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o $R -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_$R.fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o $R -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_$R.write.log 2>&1
-python - <<PY
-import csv, json, glob
-out = {}
-for name in ("fetch", "write"):
-    tot = 0.0; n = 0
-    for f in glob.glob("gpurun_out/prof_$R/%s/*counter_collection.csv" % name):
-        for r in csv.DictReader(open(f)):
-            if "mlrt_render_kernel" in r["Kernel_Name"]:
-                tot += float(r["Counter_Value"]); n += 1
-    out[name + "_size_kb_per_launch"] = tot
-# gfx950: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): the scene blob is staged with 16 B/lane loads
-out["hbm_bytes_per_launch"] = (2.0 * out["fetch_size_kb_per_launch"] + out["write_size_kb_per_launch"]) * 1024.0
-out["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch of the C2 render; FETCH_SIZE doubled per the gfx950 correction"
-json.dump(out, open("gpurun_out/hbm_traffic_$R.json", "w"), indent=1); print(out)
-PY
+R=${1:-r02}
+ROOT=$GRAFT_REPO_ROOT
+cd $ROOT
+python3 bench.py --steps 100 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err; tail -c 600 gpurun_out/${R}_bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -o $R -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${R}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_c4 -o ${R}_c4 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --config c4 > gpurun_out/${R}_trace_c4.log 2>&1
+bash tools/gpu_pmc.sh c2 fp64 $R > gpurun_out/${R}_pmc_c2_f64.log 2>&1
+bash tools/gpu_pmc.sh c2 fp32 $R > gpurun_out/${R}_pmc_c2_f32.log 2>&1
+bash tools/gpu_pmc.sh c4 fp32 $R > gpurun_out/${R}_pmc_c4_f32.log 2>&1
+bash tools/gpu_pmc.sh c4 fp64 $R > gpurun_out/${R}_pmc_c4_f64.log 2>&1
+tools/microbench/bin/valu_issue > gpurun_out/${R}_valu_issue.txt 2>&1
+python3 tests/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > gpurun_out/${R}_strong_scaling_probe.txt
+MLRT_PREC=1 python3 tests/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu >> gpurun_out/${R}_strong_scaling_probe.txt
+ls gpurun_out/${R}_trace gpurun_out/${R}_trace_c4
