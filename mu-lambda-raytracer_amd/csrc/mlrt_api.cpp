@@ -24,7 +24,8 @@
     int mlrt_block_threads_##sfx(int variant);                                                                                     \
     int mlrt_acc_bytes_per_wave_##sfx(void);                                                                                       \
     int mlrt_lds_frame_bytes_##sfx(void);                                                                                          \
-    int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);
+    int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);                                                          \
+    int mlrt_perlin_in_hbm_##sfx(void);
 extern "C" {
 MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
@@ -55,13 +56,14 @@ struct KernelBuild {
     int (*lds_frame_bytes)(void);
     int (*occupancy)(int, int, size_t);
     int (*probe)(int, const void*, int, const void*, const void*, void*, void*, int, hipStream_t);  // debug library only, else nullptr
+    int (*perlin_in_hbm)(void);
 };
 #ifdef MLRT_DEBUG_BUILD
 #define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
 #else
 #define MLRT_PROBE_OF(sfx) nullptr
 #endif
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx)}
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -408,13 +410,13 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
     return off;
 }
 
-// `wraps`: bounding-box entries in front of sphere leaves and in front of the top-level
+// `wraps`: bounding-box entries in front of sphere leaves (`wrap_leaves`) and in front of the top-level
 // entries whose miss a box can prove (primitives, medium boundaries, whole transform brackets); `sah`: SAH device BVHs.
 // None of it changes a closest hit or the conditions under which a medium draws (a ray that misses the boundary's box
 // misses the boundary: volumes.rs:27-34 returns None before drawing).  The strict build packs the reference structure
 // verbatim (wraps = sah = false, Round::EXACT).
 template <typename R, typename M>
-Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool sah, bool solid_only, bool payload_all, Round round) {
+Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool wrap_leaves, bool sah, bool solid_only, bool payload_all, Round round) {
     Packed<R, M> P;
     constexpr bool kCull32 = sizeof(R) == 4;
     P.entries.payload_all = payload_all; P.entries.round = round;
@@ -442,11 +444,11 @@ Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool sah, bool solid_only, bo
                     prim_bounds(s, s.prim_refs[refs[k]], items[k].b);
                     for (int a = 0; a < 3; a++) items[k].c[a] = 0.5 * (items[k].b.lo[a] + items[k].b.hi[a]);
                 }
-                bounds = emit_sah<R>(s, items, 0, items.size(), body, wraps);
+                bounds = emit_sah<R>(s, items, 0, items.size(), body, wraps && wrap_leaves);
                 bounded = true;
             } else {
                 int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
-                emit_subtree<R>(s, root, body, budget, wraps);
+                emit_subtree<R>(s, root, body, budget, wraps && wrap_leaves);
                 if (root >= 0) { for (int k = 0; k < 3; k++) { bounds.lo[k] = s.bvh_nodes[root].bounds_min[k]; bounds.hi[k] = s.bvh_nodes[root].bounds_max[k]; } bounded = true; }
                 else bounded = prim_bounds(s, s.prim_refs[~root], bounds);
             }
@@ -532,9 +534,10 @@ Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool sah, bool solid_only, bo
     P.off_nodes = append(P.blob, P.entries.nodes);
     P.off_materials = append(P.blob, P.materials);
     P.off_textures = append(P.blob, P.textures);
-    P.off_perlin_vec = append(P.blob, P.perlin_vec);
-    P.off_perlin_perm = append(P.blob, P.perlin_perm);
     P.off_sphere_index = append(P.blob, P.sphere_index);
+    while (P.blob.size() % 16) P.blob.push_back(0);
+    P.off_perlin_vec = append(P.blob, P.perlin_vec);  // (the Perlin tables end the blob: the f64 builds stage everything before them in LDS)
+    P.off_perlin_perm = append(P.blob, P.perlin_perm);
     while (P.blob.size() % 16) P.blob.push_back(0);
     return P;
 }
@@ -550,7 +553,7 @@ struct mlrt_context {
     const KernelBuild* build = nullptr;
     int32_t n_cus = 0;
     unsigned char* d_blob = nullptr;
-    int32_t blob_bytes = 0;
+    int32_t blob_bytes = 0, lds_blob_bytes = 0;
     int32_t off[6] = {0, 0, 0, 0, 0, 0};
     int32_t n_nodes = 0, n_sphere_index = 0;
     std::vector<unsigned char*> d_image_pixels;
@@ -665,7 +668,7 @@ bool primary_lists_wanted(const mlrt_context* c, const mlrt_params* p) {
 template <typename R>
 void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb,
                  double* d_accum, KParams<R>& K) {
-    K.blob = c->d_blob; K.blob_bytes = c->blob_bytes;
+    K.blob = c->d_blob; K.blob_bytes = c->blob_bytes; K.lds_blob_bytes = c->lds_blob_bytes;
     K.off_nodes = c->off[0]; K.off_materials = c->off[1]; K.off_textures = c->off[2];
     K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
     K.off_sphere_index = c->off[5]; K.n_sphere_index = c->n_sphere_index;
@@ -889,16 +892,28 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
             c->n_sphere_index = (int32_t)P.sphere_index.size();
         };
         const bool wraps = !strict && options->leaf_wrap != 0, sah = !strict && options->sah != 0;
+        // what of a blob of `bytes` (Perlin tables at `off_perlin`) must fit the LDS next to the waves' accumulators
+        const size_t lds_limit = 160 * 1024;
+        const size_t lds_other = (size_t)(c->block_threads / 64) * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
+        auto fits_lds = [&](const auto& P) { return (size_t)(c->build->perlin_in_hbm() ? P.off_perlin_vec : (int32_t)P.blob.size()) + lds_other <= lds_limit; };
         if (precision == MLRT_PRECISION_FP32) {
-            auto P = pack<float, float>(*scene, wraps, sah, solid_only, false, Round::OUTWARD);
+            auto P = pack<float, float>(*scene, wraps, true, sah, solid_only, false, Round::OUTWARD);
             take(P);
         } else if (precision == MLRT_PRECISION_FP64 && !options->cull_f64) {
             // product f64: f32 culling entries (rigorously outward), every primitive's f64 parameters in payload slots
-            auto P = pack<float, double>(*scene, wraps, sah, solid_only, true, Round::RIGOROUS);
-            take(P);
+            auto P = pack<float, double>(*scene, wraps, true, sah, solid_only, true, Round::RIGOROUS);
+            if (wraps && options->lds_scene != 0 && !fits_lds(P)) {
+                // The boxes in front of the sphere leaves are a third of a sphere-heavy scene's entries (final_scene: 1000 of
+                // 5638 slots): without them its f64 blob fits the LDS.  A walk over LDS-resident entries with twice the
+                // sphere tests beats a walk through L2 with the cheap culls (C4 f64, measured) - and neither changes a colour sum.
+                auto Q = pack<float, double>(*scene, wraps, false, sah, solid_only, true, Round::RIGOROUS);
+                if (fits_lds(Q)) take(Q); else take(P);
+            } else {
+                take(P);
+            }
         } else {
             // cull_f64: the same culling structure over f64 entries; strict: the reference's structure verbatim
-            auto P = pack<double, double>(*scene, wraps, sah, solid_only, false, strict ? Round::EXACT : Round::OUTWARD);
+            auto P = pack<double, double>(*scene, wraps, true, sah, solid_only, false, strict ? Round::EXACT : Round::OUTWARD);
             take(P);
         }
         c->blob_bytes = (int32_t)blob.size();
@@ -937,9 +952,10 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         // (the strict build is a test instrument: small workgroups reading the blob through L2)
         const int waves = c->block_threads / 64;
         const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
-        const size_t lds_limit = 160 * 1024;
-        c->lds_scene = !strict && blob.size() + acc <= lds_limit && options->lds_scene != 0;
-        c->dyn_lds = (c->lds_scene ? blob.size() : 0) + acc;
+        // (f64 builds read the Perlin tables - the blob's tail - from HBM: they alone would keep final_scene's blob out of LDS)
+        c->lds_blob_bytes = c->build->perlin_in_hbm() ? c->off[3] : (int32_t)blob.size();
+        c->lds_scene = !strict && (size_t)c->lds_blob_bytes + acc <= lds_limit && options->lds_scene != 0;
+        c->dyn_lds = (c->lds_scene ? (size_t)c->lds_blob_bytes : 0) + acc;
         const int occ = c->build->occupancy(c->variant, c->lds_scene, c->dyn_lds);
         c->blocks_per_cu = occ > 0 ? occ : 1;
         *out = c;

@@ -3,7 +3,7 @@
 // The packed scene is ONE position-independent blob (indices, no pointers) so that it can be uploaded to HBM
 // once and staged into LDS by every workgroup with coalesced 16-byte loads:
 //
-//   [ entries | materials | textures | perlin ranvec | perlin perm ]
+//   [ entries | materials | textures | sphere index | perlin ranvec | perlin perm ]
 //
 // entries: the WHOLE world as one linear, threaded array that a ray walks front to back with a single cursor and
 // no stack.  The top-level HittableList (hittable.rs:37-69) becomes the order of the entries; every BVH
@@ -105,6 +105,7 @@ template <typename R>
 struct KParams {
     const unsigned char* blob;  // packed scene in HBM
     int32_t blob_bytes;
+    int32_t lds_blob_bytes;  // bytes of the blob a workgroup stages in LDS (the whole blob, or up to the Perlin tables: f64 builds)
     int32_t off_nodes, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
     int32_t off_sphere_index, n_sphere_index;  // u16 entry indices of the sphere entries, in entry order (the candidate pre-pass scans these)
     int32_t n_nodes;

@@ -93,7 +93,8 @@ constexpr bool kCull32 = sizeof(creal) == 4;
 static_assert(!kFast || kCull32, "the fast build has f32 entries");
 static_assert(!kStrict || !kCull32, "the strict build has f64 entries");
 constexpr bool kPayloadAll = kCull32 && !kFast;    // product f64 build: every primitive's parameters are f64 payload slots
-constexpr bool kRigorousCull = kCull32 && !kFast;  // ... and its f32 culling test may never reject what an f64 primitive test accepts
+constexpr bool kRigorousCull = kCull32 && !kFast;
+constexpr bool kPerlinInHbm = !kFast;              // f64 builds: the Perlin tables stay in HBM (they end the blob; KParams::lds_blob_bytes stops before them)  // ... and its f32 culling test may never reject what an f64 primitive test accepts
 // Outward slack of the product f64 build's culling tests: reciprocal + fma instead of the reference's division moves a
 // slab distance by a few 1e-16 relative; 1e-12 is far outside that and far inside anything a box can wrongly admit.
 constexpr double kCullSlack64 = 1.0 + 1e-12;
@@ -1185,10 +1186,10 @@ void mlrt_render_kernel(const KParams<real> P) {
         // stage the packed scene: 16 B per lane per step, fully coalesced
         const uint4* src = reinterpret_cast<const uint4*>(P.blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        const int n16 = P.blob_bytes >> 4;
+        const int n16 = P.lds_blob_bytes >> 4;  // (the f64 builds leave the Perlin tables, the blob's tail, in HBM: see kPerlinInHbm)
         for (int i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
         base = smem;
-        acc_base = smem + P.blob_bytes;
+        acc_base = smem + P.lds_blob_bytes;
     } else {
         base = P.blob;
         acc_base = smem;
@@ -1207,8 +1208,12 @@ void mlrt_render_kernel(const KParams<real> P) {
     S.nodes = reinterpret_cast<const DNode<creal>*>(base + P.off_nodes);
     S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
     S.textures = reinterpret_cast<const DTexture<real>*>(base + P.off_textures);
-    S.perlin_vec = reinterpret_cast<const real*>(base + P.off_perlin_vec);
-    S.perlin_perm = reinterpret_cast<const uint16_t*>(base + P.off_perlin_perm);
+    // Perlin tables (textures.rs:51-74; 18 KB in f32, 30 KB in f64; read by marble hits only, 0.07 per sample of final_scene): in
+    // LDS with the rest of the scene in the fast build, whose wave-level turbulence gathers from them in every other shading
+    // batch; read from HBM / L2 in the f64 builds, where they are what keeps final_scene's 181 KB blob out of the 160 KB of LDS
+    // (C4 f64: 702 -> ? ms with the entries LDS resident)
+    S.perlin_vec = reinterpret_cast<const real*>((kPerlinInHbm ? P.blob : base) + P.off_perlin_vec);
+    S.perlin_perm = reinterpret_cast<const uint16_t*>((kPerlinInHbm ? P.blob : base) + P.off_perlin_perm);
     S.images = P.images;
 
     const int n_banks = P.n_banks, bank_vals = P.bank_values;  // wave-uniform
@@ -1776,6 +1781,7 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
     }
     return (int)hipGetLastError();
 }
+extern "C" int MLRT_CAT(mlrt_perlin_in_hbm_, MLRT_SUFFIX)(void) { return MLRT_NS::kPerlinInHbm ? 1 : 0; }
 extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
 #ifdef MLRT_DEBUG_BUILD
     return 1;
