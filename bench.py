@@ -101,60 +101,19 @@ def load_profile(config, dtype):
         return None, None
 
 
-def measured_issue_rates():
-    """profiles/r02_valu_issue_microbench.txt (tools/microbench/valu_issue.hip): what the chip sustains, in wave-instructions per
-    second chip-wide, for saturating streams of ONE instruction class - the best of the occupancies measured."""
-    path = os.path.join(ROOT, "profiles", "r02_valu_issue_microbench.txt")
-    rates = {}
-    if not os.path.exists(path):
-        return rates
-    import re
-    for line in open(path):
-        m = re.match(r"(k_\w+)\s+waves/SIMD \d+:.*?;\s*([0-9.]+) Ginstr/s chip-wide", line)
-        if m:
-            rates[m.group(1)] = max(rates.get(m.group(1), 0.0), float(m.group(2)))
-    return rates
-
-
-def mix_ceiling(prof):
-    """The VALU issue rate the microbenchmark's per-class rates allow for THIS kernel's instruction mix (harmonic mean over the
-    classes rocprofv3 counts: f64 add / mul / fma, f32 and f64 transcendentals, 64-bit integer multiplies; everything else at the
-    rate of a plain 32-bit op)."""
-    rates, mix = measured_issue_rates(), prof.get("valu_mix_per_sample")
-    if not rates or not mix or not prof.get("valu_insts_per_sample"):
-        return None
-    total = prof["valu_insts_per_sample"]
-    classes = [("FMA_F64", "k_fma_f64"), ("MUL_F64", "k_mul_f64"), ("ADD_F64", "k_add_f64"), ("TRANS_F64", "k_rcp_f64"), ("TRANS_F32", "k_rcp_f32"), ("INT64", "k_mad_u64_u32")]
-    t, counted = 0.0, 0.0
-    for key, kern in classes:
-        n = mix.get(key, 0.0)
-        if n and kern in rates:
-            t += n / rates[kern]
-            counted += n
-    plain = max(rates.get("k_add_f32", 0.0), rates.get("k_xor_b32", 0.0), rates.get("k_fma_f32", 0.0))
-    if plain <= 0.0:
-        return None
-    t += max(0.0, total - counted) / plain
-    return total / t
-
-
 def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
     prof, prof_path = load_profile(config, dtype)
     out = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64 VALU instructions)", "frac": None, "traffic": None,
            "profile": prof_path, "kernel_ms": kernel_ms,
-           "peak_note": "1 wave-instruction / 2 cycles / SIMD-32 x %d SIMDs x %.1f GHz; f64 and transcendental instructions occupy the pipe 2-8x longer "
-                        "(tools/microbench/valu_issue.hip), so 1.0 is not reachable by this instruction mix" % (SIMDS, CLOCK_GHZ)}
+           "peak_note": "1 wave-instruction / 2 cycles / SIMD-32 x %d SIMDs x %.1f GHz; f64 arithmetic issues at half that rate and transcendentals at "
+                        "1/4 (f32) to 1/8 (f64) of it (tools/microbench/valu_issue.hip, profiles/r02_valu_issue_microbench.txt), so 1.0 is not reachable by "
+                        "this instruction mix" % (SIMDS, CLOCK_GHZ)}
     if prof:
         per_sample = prof["valu_insts_per_sample"]
         achieved = per_sample * my_samples / (kernel_ms * 1e-3) / 1e9
         out.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_insts_per_sample": per_sample,
                     "lane_utilisation": prof.get("lane_utilisation"), "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
                     "profile_frac_at_capture": prof.get("valu_issue_frac"), "traffic": prof.get("hbm_bytes_per_launch")})
-        ceiling = mix_ceiling(prof)
-        if ceiling:
-            out["measured_issue_ceiling"] = {"Ginstr_per_s": ceiling, "frac": achieved / ceiling, "source": "profiles/r02_valu_issue_microbench.txt",
-                                             "note": "saturating single-class instruction streams (tools/microbench/valu_issue.hip) sustain 0.55-0.63 of the 2-cycle figure "
-                                                     "for plain ops and half of that for f64; this is the same rate weighted by the kernel's instruction mix"}
         if prof.get("hbm_bytes_per_launch"):
             out["hbm_physical_GBps"] = prof["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
             out["hbm_physical_frac"] = out["hbm_physical_GBps"] / HBM_PEAK_GBS

@@ -16,7 +16,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 constexpr int kUnroll = 16;     // independent instructions per loop body (different destination registers)
-constexpr int kIters = 8192;
+constexpr int kIters = 65536;  // (launches of 4-90 ms: long enough for the clocks to settle and for the events to time)
 
 // One kernel per instruction class: OP is the asm template with %0 = in/out register of chain k, %1, %2 = constants.
 #define DEFINE_KERNEL_F32(NAME, ASM)                                                                         \
@@ -85,7 +85,7 @@ DEFINE_KERNEL_F64(k_mov_b64, "v_mov_b64 %0, %1")
 // The chip idles at a low clock and needs milliseconds of sustained load to reach its full clock, so every measurement is
 // kReps back-to-back launches of which only the last kTimed are timed; cycles are wall time x the nominal 2.4 GHz (the
 // shader-clock counter is reported next to it: it ticks at a fixed rate, not at the momentary clock).
-constexpr int kReps = 24, kTimed = 8;
+constexpr int kReps = 8, kTimed = 4;
 constexpr double kNominalGHz = 2.4;
 template <typename T, typename K>
 void run(const char* name, K kernel, int waves_per_simd, T* d_out, unsigned long long* d_cycles, int n_cus) {
