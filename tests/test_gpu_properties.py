@@ -207,15 +207,17 @@ def test_plain_c_consumer_links_and_renders(mlrt, tmp_path):
     exe = str(tmp_path / "c_abi_consumer")
     subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_consumer.c"), "-o", exe,
                     "-L", os.path.dirname(mlrt.LIB_PATH), "-lmlrt_hip", "-lm", "-Wl,-rpath," + os.path.dirname(mlrt.LIB_PATH)], check=True)
-    out = subprocess.run([exe, "120", "4", "42"], capture_output=True, text=True, check=True)
-    lines = out.stdout.split("\n")
-    assert lines[:3] == ["P3", "120 80", "255"]
-    px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 120 * 80]], dtype=np.int32).reshape(80, 120, 3)[::-1]
     w = mlrt.World("random", 42)
-    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 120, 80, 4))
-    assert np.array_equal(px, r.render())
+    r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 120, 80, 4), precision=mlrt.PRECISION_FP64)
+    ref = r.render()
     r.close()
     w.close()
+    for extra in ([], ["3"]):  # mlrt_render (one context) and mlrt_render_multi (a device list of three entries)
+        out = subprocess.run([exe, "120", "4", "42"] + extra, capture_output=True, text=True, check=True)
+        lines = out.stdout.split("\n")
+        assert lines[:3] == ["P3", "120 80", "255"]
+        px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 120 * 80]], dtype=np.int32).reshape(80, 120, 3)[::-1]
+        assert np.array_equal(px, ref), extra
 
 
 @pytest.mark.parametrize("name", ["random", "cornell_smoke", "final_scene"])
