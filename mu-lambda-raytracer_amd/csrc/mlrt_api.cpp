@@ -465,7 +465,10 @@ Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool wrap_leaves, bool sah, b
             body.leaf(s, src.prim, false);
             bounded = prim_bounds(s, src.prim, bounds);
         }
-        const bool wrap = wraps && bounded && !(src.kind == MLRT_OBJ_PRIM && src.prim.kind == MLRT_PRIM_BOX && !xf);
+        // (a Block tests its own bounds in the step, and an untransformed BVH whose root is an inner entry already opens with the
+        // box of everything in it and the same skip target: a wrapper would be the same test twice)
+        const bool root_is_box = src.kind == MLRT_OBJ_BVH && body.size() > 1 && body.nodes[0].tag == TAG_INNER && body.reloc[0] && body.nodes[0].link == body.size();
+        const bool wrap = wraps && bounded && !(src.kind == MLRT_OBJ_PRIM && src.prim.kind == MLRT_PRIM_BOX && !xf) && !(root_is_box && !xf);
         const int32_t xf_slots = xf ? entry_slots(TAG_XFORM, kCull32, payload_all) : 0;
         const int32_t after = P.entries.size() + (wrap ? 1 : 0) + xf_slots + body.size() + (xf ? 1 : 0);
         if (wrap) {
