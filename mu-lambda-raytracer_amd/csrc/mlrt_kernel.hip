@@ -843,6 +843,14 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
             if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) sphere_uv(outward, u, v);
         } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
             outward = axis_vec(c.hit_aux, (real)1);
+            if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) {
+                // the face is one of the Block's six rects (shapes.rs:172-192): u, v over its two in-plane axes, in axis order (aarects.rs:56-57)
+                double b[6];
+                prim_params<6>(S, c.hit_node, n, b);
+                const int a0 = c.hit_aux == 0 ? 1 : 0, a1 = c.hit_aux == 2 ? 1 : 2;
+                u = div_r((real)compp(po, a0) - (real)b[a0], (real)b[3 + a0] - (real)b[a0]);
+                v = div_r((real)compp(po, a1) - (real)b[a1], (real)b[3 + a1] - (real)b[a1]);
+            }
         } else if (FEAT & FEAT_RECT) {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);

@@ -242,7 +242,7 @@ def scene_primitives(mlrt):
     m_fuzz = sc.metal((0.7, 0.6, 0.5), 1.0)
     m_glass = sc.dielectric(1.5)
     m_light = sc.light(sc.t_light)
-    c = [prim_centre(k) for k in range(11)]
+    c = [prim_centre(k) for k in range(12)]
     t = tuple
     sc.add_prim(sc.sphere(t(c[0]), 1.0, m_img))            # 0: uv sphere
     sc.add_prim(sc.sphere(t(c[1]), 2.0, m_glass))          # 1: glass
@@ -255,6 +255,7 @@ def scene_primitives(mlrt):
     sc.add_prim(sc.box(t(c[8] - 1.0), t(c[8] + 1.0), m_white))   # 8: block
     sc.add_prim(sc.box(t(c[9] - (0.5, 1.0, 1.0)), t(c[9] + (0.5, 1.0, 1.0)), m_metal))  # 9: metal block
     sc.add_prim(sc.sphere(t(c[10]), 2.0, m_glass))         # 10: solid glass (total internal reflection from inside)
+    sc.add_prim(sc.box(t(c[11] - (1.0, 0.5, 2.0)), t(c[11] + (1.0, 0.5, 2.0)), m_img))  # 11: image-textured block (u, v of the face rect)
     return sc
 
 
@@ -311,7 +312,7 @@ def rays_for(name):
         R.append(list(map(float, o)) + list(map(float, d))); L.append(label)
 
     if name == "primitives":
-        C = [prim_centre(k) for k in range(11)]
+        C = [prim_centre(k) for k in range(12)]
         X, Y, Z = np.eye(3)
         c = C[0]
         # sphere_uv known answers (shapes.rs:200-214): hit the unit sphere exactly at +-x, +-y, +-z (outside, towards the centre)
@@ -366,6 +367,11 @@ def rays_for(name):
         add(c - X + Y + 10 * Z, -Z, "inplane: block: along an edge")
         add(C[9] + 0.2 * Y + 10 * Z, (0.01, 0.0, -1.0), "metal block")
         add(C[9] + 5 * Y, -Y, "metal block from above")
+        # an image texture on a Block reads the u, v of the face's rect (shapes.rs:172-192, aarects.rs:56-57): one ray per face pair
+        add(C[11] + 0.3 * X - 0.2 * Y + 10 * Z, (0.01, 0.02, -1.0), "textured block: xy face (u along x, v along y)")
+        add(C[11] - 0.6 * X + 5 * Y + 1.1 * Z, (0.02, -1.0, 0.03), "textured block: xz face (u along x, v along z)")
+        add(C[11] - 6 * X + 0.1 * Y - 1.3 * Z, (1.0, 0.02, 0.05), "textured block: yz face (u along y, v along z)")
+        add(C[11] + 0.1 * X + 0.1 * Y, (0.2, 0.1, 1.0), "textured block: from inside (exit face, back face)")
         add((300.0, 100.0, 100.0), (1.0, 1.0, 1.0), "nothing")
     elif name == "bvh":
         # The primitives of the lattice (as scene_bvh builds them), to recognise a ray that lies EXACTLY in a face plane of a
