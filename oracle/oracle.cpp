@@ -353,6 +353,8 @@ struct OrcWorld {
     std::shared_ptr<ImageData> earth;
 };
 
+namespace orc { const Hittable* orc_scene_root(void* scene); }  // oracle_scene.cpp
+
 extern "C" {
 
 void orc_pcg64_seed_from_u64_stream(uint64_t seed, int n, uint64_t* out) {
@@ -513,10 +515,10 @@ void orc_trace_ray(void* h, const double o[3], const double d[3], int max_depth,
 // rgb: [H][W][3] int32 (only the listed rows are written); accum: optional [H][W][3] f64 colour sums.
 // stats_out: optional 10 uint64: samples, rays, aabb, sphere, rect, scatters, draws, noise, texel, medium.
 // Returns the render wall time in seconds (the reference's timer window, main.rs:145-174).
-double orc_render(void* h, const double camera19[19], int width, int height, int spp, int max_depth, uint64_t seed, int rng_mode,
-                  const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out) {
+static double render_world(const World* world, const double camera19[19], int width, int height, int spp, int max_depth, uint64_t seed, int rng_mode,
+                           const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out) {
     RenderJob job;
-    job.world = ((OrcWorld*)h)->world.get();
+    job.world = world;
     const double* c = camera19;
     job.camera.origin = Point3(c[0], c[1], c[2]);
     job.camera.lower_left_corner = Point3(c[3], c[4], c[5]);
@@ -540,6 +542,22 @@ double orc_render(void* h, const double camera19[19], int width, int height, int
         stats_out[5] = st.scatters; stats_out[6] = st.draws; stats_out[7] = st.noise_evals; stats_out[8] = st.texel_fetches; stats_out[9] = st.medium_tests;
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+double orc_render(void* h, const double camera19[19], int width, int height, int spp, int max_depth, uint64_t seed, int rng_mode,
+                  const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out) {
+    return render_world(((OrcWorld*)h)->world.get(), camera19, width, height, spp, max_depth, seed, rng_mode, rows, n_rows, threads, rgb, accum, stats_out);
+}
+// The same render over an arbitrary flattened scene (oracle_scene.cpp, orc_scene_new): the randomised parity tests.
+// background_kind: 0 black, 1 gradient (bottom .. top, raytrace.rs:29-35).
+double orc_scene_render(void* scene, int background_kind, const double top[3], const double bottom[3], const double camera19[19], int width, int height,
+                        int spp, int max_depth, uint64_t seed, int rng_mode, const int* rows, int n_rows, int threads, int32_t* rgb, double* accum) {
+    World w;
+    w.name = "scene";
+    w.root = std::shared_ptr<Hittable>(std::shared_ptr<Hittable>(), const_cast<Hittable*>(orc_scene_root(scene)));  // not owned
+    w.background.kind = background_kind == 0 ? BG_BLACK : BG_GRADIENT;
+    w.background.top = Color(top[0], top[1], top[2]);
+    w.background.bottom = Color(bottom[0], bottom[1], bottom[2]);
+    return render_world(&w, camera19, width, height, spp, max_depth, seed, rng_mode, rows, n_rows, threads, rgb, accum, nullptr);
 }
 
 }  // extern "C"

@@ -154,6 +154,8 @@ PhiloxStream stream_at(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 }  // namespace
 }  // namespace orc
 
+namespace orc { const Hittable* orc_scene_root(void* scene) { return &((SceneWorld*)scene)->root; } }  // for orc_scene_render (oracle.cpp)
+
 using namespace orc;
 
 extern "C" {

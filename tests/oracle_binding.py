@@ -105,6 +105,17 @@ class OracleScene:
         self.L.orc_scene_probe_rays(self.handle, C.c_uint64(seed), len(rays), rays.ctypes.data_as(C.c_void_p), psd.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         return out
 
+    def render(self, camera19, width, height, spp, max_depth=50, seed=0, rng_mode=RNG_PHILOX_SAMPLE, background=0, top=(0.5, 0.7, 1.0), bottom=(1.0, 1.0, 1.0),
+               threads=0, want_accum=False):
+        """The whole render loop (raytrace.rs:172-198) over this scene; (rgb int32 [H][W][3], colour sums or None)."""
+        rgb = np.zeros((height, width, 3), dtype=np.int32)
+        accum = np.zeros((height, width, 3)) if want_accum else None
+        self.L.orc_scene_render.restype = C.c_double
+        self.L.orc_scene_render(C.c_void_p(self.handle), int(background), (C.c_double * 3)(*top), (C.c_double * 3)(*bottom), (C.c_double * 19)(*camera19), width, height,
+                                spp, max_depth, C.c_uint64(seed), rng_mode, None, 0, threads, rgb.ctypes.data_as(C.c_void_p),
+                                accum.ctypes.data_as(C.c_void_p) if want_accum else None)
+        return rgb, accum
+
     def texture_value(self, tex, uvp):
         uvp = np.ascontiguousarray(uvp, dtype=np.float64)
         out = np.zeros((len(uvp), 3))

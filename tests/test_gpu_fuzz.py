@@ -134,3 +134,124 @@ def test_random_scenes_one_bounce_against_the_oracle(dbg, oracle, build):
         n_total += N_RAYS; n_hit += int((e[:, 0] == 1).sum()); n_scatter += int((e[:, 11] == 1).sum())
     assert n_hit > 0.5 * n_total and n_scatter > 0.3 * n_total, (n_hit, n_scatter, n_total)  # the rays do exercise the scenes
     assert n_soft <= 0.003 * n_total, (build, n_soft, n_total)
+
+
+# ======================================================================================================================
+# Whole frames of random scenes: the megakernel itself (lane state machine, batches, tile queue, candidate lists, media
+# sequences, depth limit, accumulation, to_rgb) through the C ABI of the RELEASE library against the oracle's render of the
+# same flattened scene with the same Philox streams.  Criteria as tests/test_gpu_parity.py: f64 8-bit image equal but for
+# <= 0.05 % of the channels (libm last-ulp differences; small frames: one flipped sample is a visible share), fast build RMSE.
+def cam19(c):
+    return list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v) + [c.lens_radius]
+
+
+def render_scene_both(mlrt, oracle, scene, cam, width, height, spp, max_depth, seed, background, precision, opts=None):
+    import ctypes as C
+    orc = OracleScene(oracle, scene)
+    ref, _ = orc.render(cam19(cam), width, height, spp, max_depth=max_depth, seed=seed, background=background)
+    orc.close()
+    p = mlrt.Params()
+    p.image_width, p.image_height, p.samples_per_pixel, p.max_depth, p.seed, p.background_kind = width, height, spp, max_depth, seed, background
+    p.background_top[:] = (0.5, 0.7, 1.0); p.background_bottom[:] = (1.0, 1.0, 1.0)
+    ctx = C.c_void_p()
+    o = opts if opts is not None else mlrt.options()
+    rc = mlrt.lib().mlrt_context_create_opts(C.byref(scene), 0, precision, C.byref(o), C.byref(ctx))
+    assert rc == 0, mlrt.lib().mlrt_last_error()
+    got = np.zeros((height, width, 3), dtype=np.int32)
+    rc = mlrt.lib().mlrt_context_render(ctx, C.byref(cam), C.byref(p), None, height, got.ctypes.data_as(C.c_void_p), None, None)
+    assert rc == 0, mlrt.lib().mlrt_last_error()
+    info = (C.c_int64 * 4)()
+    mlrt.lib().mlrt_context_info(ctx, info)
+    mlrt.lib().mlrt_context_destroy(ctx)
+    return got, ref, int(info[1])  # info[1]: scene resident in LDS
+
+
+def diff(got, ref):
+    d = (got - ref).astype(np.float64)
+    return float(np.mean(d != 0)), float(np.sqrt(np.mean(d * d)) / 255.0)
+
+
+def random_camera(mlrt, rng, lo, hi, aspect, above_ground=False):
+    centre = 0.5 * (lo + hi)
+    lookat = centre + rng.uniform(-0.3, 0.3, 3) * (hi - lo)
+    away = rng.normal(size=3)
+    away /= np.linalg.norm(away)
+    lookfrom = lookat + away * rng.uniform(0.2, 2.5) * float(np.linalg.norm(hi - lo))  # sometimes among the objects, sometimes far outside
+    if above_ground:
+        lookfrom[1] = abs(lookfrom[1]) + 0.05
+    lens = rng.random() < 0.4
+    focus = float(np.linalg.norm(lookfrom - lookat))
+    return mlrt.camera_new(tuple(lookfrom), tuple(lookat), (0.0, 1.0, 0.0), float(rng.uniform(15.0, 80.0)), aspect, float(rng.uniform(0.02, 0.5)) if lens else 0.0, focus)
+
+
+@pytest.mark.parametrize("precision_name", ["fp64", "fp32"])
+def test_random_full_scenes_whole_frames(mlrt, oracle, precision_name):
+    """FULL kernel variant: the random scenes of the one-bounce test above, random cameras (pinhole and lens), both backgrounds."""
+    precision = mlrt.PRECISION_FP64 if precision_name == "fp64" else mlrt.PRECISION_FP32
+    worst = (0.0, 0.0, -1)
+    for seed in range(8):
+        sc, lo, hi = random_scene(mlrt, seed)
+        rng = np.random.default_rng(500 + seed)
+        w, h, spp = 64 + 8 * seed, 48, [8, 33, 64, 130][seed % 4]
+        cam = random_camera(mlrt, rng, lo, hi, w / h)
+        got, ref, _ = render_scene_both(mlrt, oracle, sc.to_ctypes(), cam, w, h, spp, [50, 5, 1, 12][seed % 4], 1000 + seed, int(seed % 4 != 0), precision)
+        frac, rmse = diff(got, ref)
+        assert ref.any()
+        worst = max(worst, (frac, rmse, seed))
+        if precision_name == "fp64":
+            assert frac <= 5e-4, (seed, frac, rmse)
+        else:
+            assert rmse <= 1.0e-2 / np.sqrt(spp) + 2e-4, (seed, frac, rmse)
+
+
+def sphere_scene(mlrt, seed):
+    """Solid-colour spheres only: packs as the LEAN variant (sphere-only step, primary candidate lists)."""
+    rng = np.random.default_rng(9000 + seed)
+    sc = dc.MiniScene(mlrt)
+    u = rng.uniform
+    mats = [sc.lambertian(sc.solid(*u(0.1, 0.9, 3))) for _ in range(6)] + [sc.metal(tuple(u(0.4, 1.0, 3)), float(u(0.0, 0.6))) for _ in range(3)] + [sc.dielectric(1.5)]
+    n = [1, 2, 7, 40, 300, 1500][seed % 6]
+    extent = 2.0 + n ** (1.0 / 3.0) * 1.5
+    lo, hi = np.array([-extent, 0.0, -extent]), np.array([extent, 0.6 * extent, extent])
+    prims = [sc.sphere((0.0, -1000.0, 0.0), 1000.0, mats[0])]  # the ground, as `random` has it
+    for _ in range(n):
+        prims.append(sc.sphere(tuple(u(lo, hi)), float(u(0.1, 0.9)), mats[int(rng.integers(len(mats)))]))
+    if seed % 3 == 0:
+        sc.add_bvh([prims[i] for i in rng.permutation(len(prims))])
+    else:  # some at the top level, the rest in one or two BVHs
+        k = int(rng.integers(1, min(6, len(prims)) + 1))
+        for p in prims[:k]:
+            sc.add_prim(p)
+        rest = prims[k:]
+        if rest:
+            half = len(rest) // 2 if seed % 3 == 2 else 0
+            if half:
+                sc.add_bvh(rest[:half])
+            sc.add_bvh(rest[half:])
+    return sc, lo, hi
+
+
+@pytest.mark.parametrize("precision_name", ["fp64", "fp32"])
+def test_random_sphere_scenes_whole_frames(mlrt, oracle, precision_name):
+    """LEAN kernel variant with the primary candidate lists: 1 .. 1500 random spheres, cameras outside and among them (a frustum
+    apex inside a sphere's box, lens or pinhole), frame sizes around the tile planner's thresholds; the same frames with the lists
+    switched off and with the scene read from HBM must be bit-identical."""
+    precision = mlrt.PRECISION_FP64 if precision_name == "fp64" else mlrt.PRECISION_FP32
+    for seed in range(12):
+        sc, lo, hi = sphere_scene(mlrt, seed)
+        rng = np.random.default_rng(700 + seed)
+        w, h = [(96, 64), (33, 17), (128, 40), (60, 60)][seed % 4]
+        spp = [16, 127, 64, 200][seed % 4]
+        cam = random_camera(mlrt, rng, lo, hi, w / h, above_ground=seed != 7)  # (seed 7: the camera inside the ground sphere, a black frame)
+        scene = sc.to_ctypes()
+        got, ref, lds = render_scene_both(mlrt, oracle, scene, cam, w, h, spp, 50 if seed % 5 else 3, 2000 + seed, 1, precision)
+        frac, rmse = diff(got, ref)
+        assert lds == 1 or len(sc.spheres) > 1000  # (1500 spheres with f64 payload slots: read from HBM / L2)
+        if precision_name == "fp64":
+            assert frac <= 5e-4, (seed, frac, rmse)
+        else:
+            assert rmse <= 1e-3, (seed, frac, rmse)
+        if seed % 2 == 0:
+            for kw in (dict(primary_lists=0), dict(lds_scene=0)):
+                other, _, _ = render_scene_both(mlrt, oracle, scene, cam, w, h, spp, 50 if seed % 5 else 3, 2000 + seed, 1, precision, opts=mlrt.options(**kw))
+                assert np.array_equal(other, got), (seed, kw)
