@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/mlrt.h"
@@ -80,10 +81,20 @@ void validate(const mlrt_scene& s) {
     MLRT_REQUIRE(s.n_spheres >= 0 && s.n_boxes >= 0 && s.n_rects >= 0 && s.n_prim_refs >= 0 && s.n_bvh_nodes >= 0 && s.n_bvhs >= 0 &&
                      s.n_transforms >= 0 && s.n_materials >= 0 && s.n_textures >= 0 && s.n_images >= 0 && s.n_perlins >= 0,
                  "negative element count");
+    MLRT_REQUIRE((s.n_spheres == 0 || s.spheres) && (s.n_boxes == 0 || s.boxes) && (s.n_rects == 0 || s.rects) && (s.n_prim_refs == 0 || s.prim_refs) &&
+                     (s.n_bvh_nodes == 0 || s.bvh_nodes) && (s.n_bvhs == 0 || s.bvhs) && (s.n_transforms == 0 || s.transforms) && (s.n_materials == 0 || s.materials) &&
+                     (s.n_textures == 0 || s.textures) && (s.n_images == 0 || s.images) && (s.n_perlins == 0 || s.perlins),
+                 "an array with a positive element count is NULL");
+    // Geometry must be finite: the reference would render NaNs, the device structure (bounds, SAH sort) cannot be built from them.
+    auto finite = [](const double* v, int n) { for (int k = 0; k < n; k++) if (!std::isfinite(v[k])) return false; return true; };
     auto mat_ok = [&](int32_t m) { return m >= 0 && m < s.n_materials; };
-    for (int i = 0; i < s.n_spheres; i++) MLRT_REQUIRE(mat_ok(s.spheres[i].material), "sphere material out of range");
+    for (int i = 0; i < s.n_spheres; i++) {
+        MLRT_REQUIRE(mat_ok(s.spheres[i].material), "sphere material out of range");
+        MLRT_REQUIRE(finite(s.spheres[i].center, 3) && std::isfinite(s.spheres[i].radius), "sphere centre / radius is not finite");
+    }
     for (int i = 0; i < s.n_boxes; i++) {
         MLRT_REQUIRE(mat_ok(s.boxes[i].material), "box material out of range");
+        MLRT_REQUIRE(finite(s.boxes[i].min, 3) && finite(s.boxes[i].max, 3), "box corner is not finite");
         // Block::new(p0, p1) with a corner pair that is not (min, max) builds degenerate rects in the reference (AARect::new keeps
         // a1_v0 as given, aarects.rs:39 - quirk Q2 - so a side can come out with a1_v0 > a1_v1 and never be hit): not a shape
         // anyone means, and not what the device's slab form of a Block would render
@@ -94,6 +105,7 @@ void validate(const mlrt_scene& s) {
         MLRT_REQUIRE(mat_ok(r.material), "rect material out of range");
         // aarects.rs:9-17 other(): only (X,Y), (X,Z), (Y,Z) are legal, anything else panics
         MLRT_REQUIRE((r.a0 == 0 && r.a1 == 1) || (r.a0 == 0 && r.a1 == 2) || (r.a0 == 1 && r.a1 == 2), "rect axes must be (0,1), (0,2) or (1,2)");
+        MLRT_REQUIRE(std::isfinite(r.a0_v0) && std::isfinite(r.a0_v1) && std::isfinite(r.a1_v0) && std::isfinite(r.a1_v1) && std::isfinite(r.plane), "rect coordinate is not finite");
     }
     auto prim_ok = [&](const mlrt_prim_ref& p) {
         if (p.kind == MLRT_PRIM_SPHERE) return p.index >= 0 && p.index < s.n_spheres;
@@ -103,9 +115,29 @@ void validate(const mlrt_scene& s) {
     };
     for (int i = 0; i < s.n_prim_refs; i++) MLRT_REQUIRE(prim_ok(s.prim_refs[i]), "prim_ref out of range");
     auto child_ok = [&](int32_t c) { return c >= 0 ? c < s.n_bvh_nodes : (~c) < s.n_prim_refs; };
-    for (int i = 0; i < s.n_bvh_nodes; i++) MLRT_REQUIRE(child_ok(s.bvh_nodes[i].left) && child_ok(s.bvh_nodes[i].right), "bvh child out of range");
-    for (int i = 0; i < s.n_bvhs; i++) MLRT_REQUIRE(s.bvhs[i].root == MLRT_BVH_EMPTY || child_ok(s.bvhs[i].root), "bvh root out of range");
-    for (int i = 0; i < s.n_transforms; i++) MLRT_REQUIRE(!s.transforms[i].has_rotate || (s.transforms[i].axis >= 0 && s.transforms[i].axis <= 2), "rotation axis out of range");
+    for (int i = 0; i < s.n_bvh_nodes; i++) {
+        MLRT_REQUIRE(child_ok(s.bvh_nodes[i].left) && child_ok(s.bvh_nodes[i].right), "bvh child out of range");
+        MLRT_REQUIRE(finite(s.bvh_nodes[i].bounds_min, 3) && finite(s.bvh_nodes[i].bounds_max, 3), "bvh node bounds are not finite");
+    }
+    for (int i = 0; i < s.n_bvhs; i++) {
+        MLRT_REQUIRE(s.bvhs[i].root == MLRT_BVH_EMPTY || child_ok(s.bvhs[i].root), "bvh root out of range");
+        // a tree (bhv.rs:109-120: every Node owns its children): a walk that visits more than every node and leaf once has met a cycle
+        int64_t budget = 2 * (int64_t)s.n_bvh_nodes + s.n_prim_refs + 2;
+        std::vector<int32_t> stack;
+        if (s.bvhs[i].root >= 0) stack.push_back(s.bvhs[i].root);
+        while (!stack.empty()) {
+            const int32_t node = stack.back();
+            stack.pop_back();
+            MLRT_REQUIRE(--budget >= 0, "bvh is cyclic or larger than its node count allows");
+            if (s.bvh_nodes[node].left >= 0) stack.push_back(s.bvh_nodes[node].left);
+            if (s.bvh_nodes[node].right >= 0) stack.push_back(s.bvh_nodes[node].right);
+        }
+    }
+    for (int i = 0; i < s.n_transforms; i++) {
+        const mlrt_transform& t = s.transforms[i];
+        MLRT_REQUIRE(!t.has_rotate || (t.axis >= 0 && t.axis <= 2), "rotation axis out of range");
+        MLRT_REQUIRE((!t.has_rotate || (std::isfinite(t.sin_theta) && std::isfinite(t.cos_theta))) && (!t.has_translate || finite(t.offset, 3)), "transform is not finite");
+    }
     for (int i = 0; i < s.n_textures; i++) {
         const mlrt_texture& t = s.textures[i];
         if (t.kind == MLRT_TEX_IMAGE) MLRT_REQUIRE(t.index >= 0 && t.index < s.n_images, "image texture index out of range");
@@ -113,8 +145,22 @@ void validate(const mlrt_scene& s) {
         else if (t.kind == MLRT_TEX_CHECKER) MLRT_REQUIRE(t.index >= 0 && t.index < s.n_textures && t.index2 >= 0 && t.index2 < s.n_textures, "checker texture index out of range");
         else MLRT_REQUIRE(t.kind == MLRT_TEX_SOLID, "unknown texture kind");
     }
-    for (int i = 0; i < s.n_images; i++) MLRT_REQUIRE(s.images[i].width > 0 && s.images[i].height > 0 && s.images[i].rgb, "empty image");
-    for (int i = 0; i < s.n_perlins; i++) MLRT_REQUIRE(s.perlins[i].ranvec && s.perlins[i].perm, "perlin table is NULL");
+    // Checker(odd, even) owns its two textures in the reference (textures.rs:28-38): a tree.  The device follows the indices for
+    // at most 8 levels, so deeper nesting - and any cycle - is refused rather than rendered differently.
+    std::function<int(int32_t, int)> checker_depth = [&](int32_t tex, int depth) -> int {
+        if (depth > 8 || s.textures[tex].kind != MLRT_TEX_CHECKER) return depth;
+        return std::max(checker_depth(s.textures[tex].index, depth + 1), checker_depth(s.textures[tex].index2, depth + 1));
+    };
+    for (int i = 0; i < s.n_textures; i++) MLRT_REQUIRE(checker_depth(i, 0) <= 8, "checker textures nest deeper than 8 levels (or refer to themselves)");
+    for (int i = 0; i < s.n_images; i++) {
+        MLRT_REQUIRE(s.images[i].width > 0 && s.images[i].height > 0 && s.images[i].rgb, "empty image");
+        MLRT_REQUIRE((int64_t)s.images[i].width * s.images[i].height <= (int64_t)1 << 28, "image texture larger than 2^28 texels");
+    }
+    for (int i = 0; i < s.n_perlins; i++) {
+        MLRT_REQUIRE(s.perlins[i].ranvec && s.perlins[i].perm, "perlin table is NULL");
+        // the three permutations index the 1024 gradient vectors (textures.rs:113-117): anything else would read outside the table
+        for (int k = 0; k < 3072; k++) MLRT_REQUIRE(s.perlins[i].perm[k] >= 0 && s.perlins[i].perm[k] < 1024, "perlin permutation entry outside 0..1023");
+    }
     for (int i = 0; i < s.n_materials; i++) {
         const mlrt_material& m = s.materials[i];
         MLRT_REQUIRE(m.kind >= MLRT_MAT_LAMBERTIAN && m.kind <= MLRT_MAT_ISOTROPIC, "unknown material kind");
@@ -126,7 +172,7 @@ void validate(const mlrt_scene& s) {
         MLRT_REQUIRE(o.transform >= -1 && o.transform < s.n_transforms, "object transform out of range");
         if (o.kind == MLRT_OBJ_BVH) MLRT_REQUIRE(o.bvh >= 0 && o.bvh < s.n_bvhs, "object bvh out of range");
         else if (o.kind == MLRT_OBJ_PRIM) MLRT_REQUIRE(prim_ok(o.prim), "object primitive out of range");
-        else if (o.kind == MLRT_OBJ_MEDIUM) MLRT_REQUIRE(prim_ok(o.prim) && mat_ok(o.phase_material), "medium boundary/material out of range");
+        else if (o.kind == MLRT_OBJ_MEDIUM) MLRT_REQUIRE(prim_ok(o.prim) && mat_ok(o.phase_material) && std::isfinite(o.neg_inv_density), "medium boundary/material out of range or density not finite");
         else MLRT_REQUIRE(false, "unknown object kind");
     }
 }

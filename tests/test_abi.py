@@ -110,3 +110,42 @@ def test_options_defaults_and_environment(mlrt, monkeypatch):
     monkeypatch.setenv("MLRT_CULL_F64", "1")
     mlrt.lib().mlrt_options_from_env(C.byref(o))
     assert o.sah == 0 and o.cull_f64 == 1 and o.n_tail == 2 and list(o.tail)[:2] == [64, 128]
+
+
+def test_malformed_scenes_are_refused_with_a_message(mlrt):
+    """validate() (csrc/mlrt_api.cpp) runs before any device call: every malformed field below must come back as MLRT_ERR_INVALID
+    with a message naming it - never a crash, a hang or a silently different picture."""
+    import directed_cases as dc
+
+    def rc_of(mutate):
+        sc = dc.scene_bvh(mlrt)
+        scene = sc.to_ctypes()
+        mutate(scene)
+        ctx = C.c_void_p()
+        rc = mlrt.lib().mlrt_context_create(C.byref(scene), 0, mlrt.PRECISION_FP64, C.byref(ctx))
+        assert not ctx.value
+        return rc, mlrt.lib().mlrt_last_error().decode()
+
+    def nan_sphere(s): s.spheres[3].center[1] = float("nan")
+    def inf_radius(s): s.spheres[0].radius = float("inf")
+    def nan_box(s): s.boxes[2].max[0] = float("nan")
+    def nan_node(s): s.bvh_nodes[1].bounds_min[2] = float("nan")
+    def nan_offset(s): s.transforms[0].offset[0] = float("inf")
+    def null_array(s): s.spheres = C.cast(None, type(s.spheres))
+    def bad_child(s): s.bvh_nodes[0].left = s.n_bvh_nodes
+    def cyclic(s): s.bvh_nodes[s.bvhs[0].root].left = s.bvhs[0].root
+    def bad_material(s): s.boxes[0].material = s.n_materials
+    def bad_texture(s): s.materials[0].texture = -1
+    def self_checker(s): s.textures[4].index = 4  # base(): texture 4 is the Checker
+    def bad_perm(s): C.cast(s.perlins[0].perm, C.POINTER(C.c_int32))[5] = 1024
+    def bad_axis(s): s.transforms[0].axis = 3
+    def bad_object(s): s.objects[0].kind = 7
+    def reversed_box(s): s.boxes[1].min[1] = s.boxes[1].max[1] + 1.0
+
+    cases = [(nan_sphere, "sphere"), (inf_radius, "sphere"), (nan_box, "box"), (nan_node, "bvh node bounds"), (nan_offset, "transform"), (null_array, "NULL"),
+             (bad_child, "bvh child"), (cyclic, "cyclic"), (bad_material, "box material"), (bad_texture, "material texture"), (self_checker, "checker"),
+             (bad_perm, "perlin permutation"), (bad_axis, "rotation axis"), (bad_object, "object kind"), (reversed_box, "box min")]
+    for mutate, word in cases:
+        rc, msg = rc_of(mutate)
+        assert rc == mlrt.MLRT_ERR_INVALID, (mutate.__name__, rc, msg)
+        assert word in msg, (mutate.__name__, msg)
