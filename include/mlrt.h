@@ -213,7 +213,12 @@ const char* mlrt_last_error(void);
 int32_t mlrt_device_count(void);
 
 /* Replaces Renderer::new_with_rng: validates the scene, packs it into the device layout (threaded BVH,
- * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*. */
+ * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*.
+ * Validation happens before any device call and returns MLRT_ERR_INVALID (message in mlrt_last_error) for: no objects; a NULL
+ * array with a positive count; any index out of range (materials, textures, images, Perlin tables, primitives, BVH children,
+ * transforms); a BVH that is not a tree; non-finite geometry (spheres, boxes, rects, BVH bounds, transforms, medium density);
+ * a box with min > max; rect axes other than (0,1), (0,2), (1,2); Checker textures nested deeper than 8 levels or cyclic;
+ * a Perlin permutation entry outside 0..1023; unknown kinds. */
 int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out); /* options from the environment */
 int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_t precision, const mlrt_options* options, mlrt_context** out);
 void mlrt_context_destroy(mlrt_context* ctx);
