@@ -5,7 +5,7 @@
 // The render itself is mlrt_context_render (include/mlrt.h) on the MI355X; there is no CPU path here.
 // Flags beyond the reference: --precision=fp64|fp32 (default fp64: the reference's arithmetic, /root/reference/src/vec.rs:5-8;
 // fp32 is the fast mixed-precision mode), --device=N, --gpus=N (the frame's rows over devices 0..N-1 of this node, one
-// gather: mlrt_multi_*) or --devices=a,b,c, --format=p3|p6 (p6: the same image as binary PPM), --earthmap=<earthmap.jpg or a
+// gather: mlrt_multi_*) or --devices=a,b,c, --format=p3|p6|png (p6 / png: the same image as binary PPM / PNG), --earthmap=<earthmap.jpg or a
 // binary P6> (default: earthmap.jpg in the working directory, as the reference; then earthmap.ppm).
 // Progress ("Remaining: NN%", main.rs:157-173) is shown only when stderr is a terminal: it splits the frame into a few
 // synchronised launches, which a timed or piped run should not pay for.
@@ -18,6 +18,7 @@
 // the packed scene and the device context stay resident; only the camera changes.
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -50,6 +51,54 @@ bool read_p6(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h)
 
 bool parse_vector(const std::string& s, double out[3]) {  // main.rs:54-62
     return std::sscanf(s.c_str(), "%lf,%lf,%lf", &out[0], &out[1], &out[2]) == 3;
+}
+
+// PNG (8-bit RGB, filter 0 on every row, deflate in STORED blocks: no compression library in this image and none needed - the
+// file is for viewing, 3 bytes per pixel like the P6).  rgb: [H][W][3], row 0 = bottom.
+int32_t write_png(FILE* f, const int32_t* rgb, int32_t width, int32_t height) {
+    static uint32_t crc_table[256];
+    if (!crc_table[1])
+        for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; }
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { for (int k = 3; k >= 0; k--) v.push_back((uint8_t)(x >> (8 * k))); };
+    bool ok = true;
+    auto chunk = [&](const char type[4], const std::vector<uint8_t>& data) {
+        std::vector<uint8_t> out;
+        be32(out, (uint32_t)data.size());
+        out.insert(out.end(), type, type + 4);
+        out.insert(out.end(), data.begin(), data.end());
+        uint32_t c = 0xFFFFFFFFu;
+        for (size_t i = 4; i < out.size(); i++) c = crc_table[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+        be32(out, c ^ 0xFFFFFFFFu);
+        ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    };
+    static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    ok = std::fwrite(signature, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0};  // bit depth 8, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk("IHDR", ihdr);
+    std::vector<uint8_t> raw;  // filter byte + row, top row first
+    raw.reserve((size_t)height * ((size_t)width * 3 + 1));
+    for (int32_t j = height - 1; j >= 0; j--) {
+        raw.push_back(0);
+        for (size_t e = 0; e < (size_t)width * 3; e++) raw.push_back((uint8_t)rgb[(size_t)j * width * 3 + e]);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};  // zlib header: deflate, 32 KiB window, no preset dictionary
+    uint32_t a = 1, b = 0;                  // Adler-32 of the raw bytes
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        for (size_t i = 0; i < n; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    return ok ? MLRT_OK : MLRT_ERR_INVALID;
 }
 
 struct Progress {
@@ -156,7 +205,7 @@ int main(int argc, char** argv) {
     mlrt_camera_new(lookfrom, lookat, up, fov, aspect_ratio, std::atof(opt["aperture"].c_str()), focus_dist, &camera);
 
     if (opt["precision"] != "fp64" && opt["precision"] != "fp32") { std::fprintf(stderr, "mlrt: --precision must be fp64 or fp32\n"); return 2; }
-    if (opt["format"] != "p3" && opt["format"] != "p6") { std::fprintf(stderr, "mlrt: --format must be p3 or p6\n"); return 2; }
+    if (opt["format"] != "p3" && opt["format"] != "p6" && opt["format"] != "png") { std::fprintf(stderr, "mlrt: --format must be p3, p6 or png\n"); return 2; }
     const int32_t precision = opt["precision"] == "fp64" ? MLRT_PRECISION_FP64 : MLRT_PRECISION_FP32;
     std::vector<int32_t> rgb((size_t)params.image_width * params.image_height * 3);
     std::vector<int32_t> devices;  // --gpus=N | --devices=a,b,c: the multi-device path
@@ -173,6 +222,7 @@ int main(int argc, char** argv) {
     }
     auto write_image = [&](FILE* f) -> int32_t {
         if (opt["format"] == "p3") return mlrt_write_p3(f, rgb.data(), params.image_width, params.image_height);
+        if (opt["format"] == "png") return write_png(f, rgb.data(), params.image_width, params.image_height);
         // binary PPM of the same image, top row first (the reference prints P3 only, main.rs:144,175-179)
         std::fprintf(f, "P6\n%d %d\n255\n", params.image_width, params.image_height);
         std::vector<uint8_t> line((size_t)params.image_width * 3);

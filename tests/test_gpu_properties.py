@@ -130,6 +130,20 @@ def test_cli_is_a_drop_in_for_the_reference_command_line(mlrt, oracle, tmp_path)
         assert raw.startswith(header) and len(raw) == len(header) + 400 * 266 * 3
         img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(266, 400, 3)[::-1].astype(np.int32)
         assert np.array_equal(img, ref64), extra
+    # --format=png: the same image again (8-bit RGB, stored deflate blocks): chunk CRCs, the zlib stream and the pixels
+    import struct, zlib
+    png = subprocess.run(args[:-1] + ["--format=png"], capture_output=True, check=True).stdout
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(png):
+        n, kind = struct.unpack(">I4s", png[pos:pos + 8])
+        body = png[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"] and chunks[0][1] == struct.pack(">IIBBBBB", 400, 266, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(266, 1 + 400 * 3)
+    assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(266, 400, 3)[::-1].astype(np.int32), ref64)
     fast = subprocess.run(args + ["--precision=fp32"], capture_output=True, check=True).stdout
     r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8), precision=mlrt.PRECISION_FP32)
     assert np.array_equal(np.frombuffer(fast[len(b"P6\n400 266\n255\n"):], dtype=np.uint8).reshape(266, 400, 3)[::-1].astype(np.int32), r.render())
