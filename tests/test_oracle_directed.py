@@ -64,3 +64,29 @@ def test_a_block_with_reversed_corners_is_rejected(mlrt):
     ctx = C.c_void_p()
     rc = mlrt.lib().mlrt_context_create(C.byref(sc.to_ctypes()), 0, mlrt.PRECISION_FP64, C.byref(ctx))
     assert rc == mlrt.MLRT_ERR_INVALID and b"box min" in mlrt.lib().mlrt_last_error()
+
+
+@pytest.mark.parametrize("name,width,height,spp", [("simple", 40, 24, 4), ("random", 48, 32, 4), ("random_chk", 32, 24, 4), ("simple_light", 32, 24, 8),
+                                                   ("cornell_box", 24, 24, 8), ("cornell_smoke", 24, 24, 8), ("earth", 32, 24, 4), ("debug_perlin", 24, 24, 4),
+                                                   ("final_scene", 24, 24, 8)])
+def test_scene_oracle_is_the_world_oracle(mlrt, oracle, earthmap, name, width, height, spp):
+    """The oracle over an arbitrary FLATTENED scene (oracle_scene.cpp: the checker of tests/test_gpu_fuzz.py and of the directed
+    probes) renders the host's flattened form of every kind of world to the very same colour sums as the oracle's own world
+    builders (oracle.cpp build_world: the implementation the golden images and the reference's known answers pin) - both RNG
+    contracts.  So a scene handed over the C ABI means to the checker what the reference's world means."""
+    from oracle_binding import RNG_PCG_ROW, RNG_PHILOX_SAMPLE
+    earth = earthmap if name in ("earth", "final_scene") else None
+    pw = mlrt.World(name, 42, earth)
+    ow = oracle.world(name, 42, earth)
+    cam = mlrt.default_camera(pw, width / height, 0.05, None)
+    cam19 = list(cam.origin) + list(cam.lower_left_corner) + list(cam.horizontal) + list(cam.vertical) + list(cam.u) + list(cam.v) + [cam.lens_radius]
+    p = mlrt.make_params(pw, width, height, spp)
+    osc = oracle.scene(pw.scene.contents if hasattr(pw.scene, "contents") else pw.scene)
+    for mode in (RNG_PHILOX_SAMPLE, RNG_PCG_ROW):
+        ref_rgb, ref_acc, _, _ = ow.render(cam19, width, height, spp, max_depth=12, seed=42, rng_mode=mode, want_accum=True)
+        got_rgb, got_acc = osc.render(cam19, width, height, spp, max_depth=12, seed=42, rng_mode=mode, background=int(p.background_kind),
+                                      top=tuple(p.background_top), bottom=tuple(p.background_bottom), want_accum=True)
+        assert np.array_equal(got_acc, ref_acc) and np.array_equal(got_rgb, ref_rgb), (name, mode)
+    osc.close()
+    ow.close()
+    pw.close()
