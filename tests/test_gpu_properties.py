@@ -355,3 +355,50 @@ def test_kernel_watchdog_ends_a_stalled_launch_with_an_error(mlrt):
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=120)
     lines = [ln for ln in out.stdout.split("\n") if ln.startswith(("ERR", "OK", "NO"))]
     assert lines == ["ERR %d True True" % mlrt.MLRT_ERR_HIP, "OK True"] * 2, (out.stdout, out.stderr[-1500:])
+
+
+def test_one_context_renders_frames_of_changing_size_and_contexts_run_side_by_side(mlrt, earthmap):
+    """A context is the scene on the device, not a frame: the same context renders frames of other sizes, sample counts, depths and
+    cameras one after the other (its accumulation buffer grows when it must and is left zeroed by every frame), each equal to the
+    frame of a fresh context.  And contexts are independent: two host threads, each with its own context and stream, render at
+    the same time (the documented rule is one call at a time PER CONTEXT) and get the frames they get alone."""
+    import threading
+    worlds = {"random": mlrt.World("random", 42), "final_scene": mlrt.World("final_scene", 42, earthmap)}
+    frames = [(64, 40, 8, 50, 0.0), (200, 120, 3, 2, 0.1), (33, 17, 130, 50, 0.0), (64, 40, 8, 50, 0.0), (160, 160, 1, 0, 0.0)]
+    for name, w in worlds.items():
+        for precision in (mlrt.PRECISION_FP64, mlrt.PRECISION_FP32):
+            shared = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 64, 40, 8), precision=precision)
+            for width, height, spp, depth, aperture in frames:
+                cam = mlrt.default_camera(w, width / height, aperture)
+                params = mlrt.make_params(w, width, height, spp, depth)
+                shared.camera, shared.params = cam, params
+                got = shared.render()
+                fresh = mlrt.Renderer(w, cam, params, precision=precision)
+                assert np.array_equal(got, fresh.render()), (name, precision, width, height, spp, depth)
+                fresh.close()
+            shared.close()
+    # two threads, two contexts (different scenes and precisions), several frames each
+    jobs = [("random", mlrt.PRECISION_FP64, 240, 160, 24), ("final_scene", mlrt.PRECISION_FP32, 120, 120, 16)]
+    alone, together = [], [None, None]
+    renderers = []
+    for name, precision, width, height, spp in jobs:
+        w = worlds[name]
+        r = mlrt.Renderer(w, mlrt.default_camera(w, width / height), mlrt.make_params(w, width, height, spp), precision=precision)
+        renderers.append(r)
+        alone.append(r.render())
+
+    def work(k):
+        for _ in range(4):
+            img = renderers[k].render()
+            together[k] = img if together[k] is None or np.array_equal(together[k], img) else np.zeros_like(img)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        assert np.array_equal(together[k], alone[k]), jobs[k]
+        renderers[k].close()
+    for w in worlds.values():
+        w.close()
