@@ -15,6 +15,8 @@
  * library copies what it needs to the device.  Errors: non-zero return + mlrt_last_error() (thread-local
  * message); no exception crosses the ABI.  All geometry is f64 at the ABI, as in the reference (src/vec.rs:5-8).
  * There is NO CPU fallback: every compute entry point fails with MLRT_ERR_NO_DEVICE when no HIP device exists.
+ * Threads: one call at a time per context (the reference's render() is called once, from the main thread, and blocks:
+ * src/main.rs:157); different contexts may be used from different threads at the same time.
  */
 #ifndef MLRT_H
 #define MLRT_H
