@@ -55,10 +55,16 @@ class RowGatherer:
         n_max = max_rows_per_rank(height, world_size, block)
         self.send = torch.zeros((n_max, width, 3), dtype=torch.uint8, device=device)
         self.image = torch.zeros((height, width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
-        self.gathered = [torch.zeros_like(self.send) for _ in range(world_size)] if (rank == 0 and world_size > 1) else None
+        # rank 0 receives into ONE buffer (the per-rank tensors dist.gather wants are views of it), so that when every rank holds the
+        # same number of rows the frame is assembled by one index_copy_ instead of one per rank
+        self.flat = torch.zeros((world_size * n_max, width, 3), dtype=torch.uint8, device=device) if (rank == 0 and world_size > 1) else None
+        self.gathered = list(self.flat.chunk(world_size, dim=0)) if self.flat is not None else None
         self.index = None
+        self.flat_index = None
         if rank == 0:
             self.index = [torch.tensor(rows_for_rank(height, r, world_size, block), dtype=torch.long, device=device) for r in range(world_size)]
+            if world_size > 1 and all(ix.numel() == n_max for ix in self.index):
+                self.flat_index = torch.cat(self.index)
 
     def gather(self, local_rows_i32):
         """local_rows_i32: int32 [n_local][W][3] (values 0..255) on this rank's device.  Returns the frame on rank 0."""
@@ -72,6 +78,9 @@ class RowGatherer:
         dist.gather(self.send, self.gathered, dst=0, group=self.group)  # the one collective of the frame
         if self.rank != 0:
             return None
+        if self.flat_index is not None:
+            self.image.index_copy_(0, self.flat_index, self.flat)
+            return self.image
         for r in range(self.world_size):
             self.image.index_copy_(0, self.index[r], self.gathered[r][: self.index[r].numel()])
         return self.image
