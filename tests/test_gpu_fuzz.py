@@ -116,13 +116,11 @@ def random_rays(seed, lo, hi, n):
 PLACES = {"unit": (1.0, (0.0, 0.0, 0.0)), "tiny": (1e-3, (0.0, 0.0, 0.0)), "far": (1.0, (1e6, -2e6, 5e5)), "large": (300.0, (1e5, 1e5, 1e5))}
 
 
-@pytest.mark.parametrize("place", sorted(PLACES))
-@pytest.mark.parametrize("build", BUILDS)
+# (the fast build's f32 geometry is not meant for coordinates of 1e6 or sizes of 1e-3: it runs the "unit" scenes only)
+@pytest.mark.parametrize("build,place", [(b, p) for b in BUILDS for p in sorted(PLACES) if b != "fp32" or p == "unit"])
 def test_random_scenes_one_bounce_against_the_oracle(dbg, oracle, build, place):
     m = dbg
     f64 = build != "fp32"
-    if not f64 and place != "unit":
-        pytest.skip("the fast build's f32 geometry is not meant for coordinates of 1e6 or sizes of 1e-3")
     n_hit = n_scatter = n_total = n_soft = 0
     for seed in range(12):
         sc, lo, hi = random_scene(m, seed, *PLACES[place])
