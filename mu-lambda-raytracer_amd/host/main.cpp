@@ -9,7 +9,8 @@
 // binary P6> (default: earthmap.jpg in the working directory, as the reference; then earthmap.ppm).
 // Progress ("Remaining: NN%", main.rs:157-173) is shown only when stderr is a terminal: it splits the frame into a few
 // synchronised launches, which a timed or piped run should not pay for.
-// Not supported: running without --seed and --randomized_rendering (ThreadRng, non-deterministic).
+// Without --seed / with --randomized_rendering (the reference's ThreadRng runs, different every time by design) the seeds come
+// from the OS's entropy source and are printed.
 //
 // Frame-sequence mode (replaces /root/reference/movie.py, which re-launches the binary - world rebuild and all - once
 // per frame): --movie_frames=N [--movie_step_degrees=0.5] [--movie_origin=x,y,z] [--movie_prefix=_movie/frame] renders N
@@ -25,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -127,9 +129,10 @@ int main(int argc, char** argv) {
     std::map<std::string, std::string> opt = {{"aspect_ratio", "16:9"}, {"image_width", "400"}, {"samples_per_pixel", "200"}, {"max_depth", "50"},
                                               {"up", "0,1.0,0"},        {"aperture", "0.0"},    {"world", "simple"},          {"precision", "fp64"},
                                               {"device", "0"},          {"format", "p3"}};
+    bool randomized_rendering = false;
     for (int i = 1; i < argc; i++) {
         std::string a(argv[i]);
-        if (a == "--randomized_rendering" || a == "-r") { std::fprintf(stderr, "mlrt: --randomized_rendering (ThreadRng) is not supported by the device path\n"); return 2; }
+        if (a == "--randomized_rendering" || a == "-r") { randomized_rendering = true; continue; }
         if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "mlrt: unexpected argument '%s'\n", a.c_str()); return 2; }
         a = a.substr(2);
         const size_t eq = a.find('=');
@@ -137,8 +140,14 @@ int main(int argc, char** argv) {
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::fprintf(stderr, "mlrt: missing value for --%s\n", a.c_str()); return 2; }
     }
-    if (!opt.count("seed")) { std::fprintf(stderr, "mlrt: --seed is required (the unseeded ThreadRng path of the reference is non-deterministic and not accelerated)\n"); return 2; }
-    const uint64_t seed = std::strtoull(opt["seed"].c_str(), nullptr, 10);
+    // main.rs:202-216: without --seed the reference draws the world AND the samples from ThreadRng, with --randomized_rendering only the
+    // samples (the world still follows --seed): runs that differ from each other by design.  Here: a seed from the OS's entropy
+    // source in the same places, printed so the run can be repeated with --seed.
+    auto entropy_seed = [] { std::random_device rd; return ((uint64_t)rd() << 32) ^ (uint64_t)rd(); };
+    const uint64_t seed = opt.count("seed") ? std::strtoull(opt["seed"].c_str(), nullptr, 10) : entropy_seed();
+    const uint64_t render_seed = (randomized_rendering && opt.count("seed")) ? entropy_seed() : seed;
+    if (!opt.count("seed")) std::fprintf(stderr, "mlrt: no --seed: using --seed=%llu\n", (unsigned long long)seed);
+    else if (randomized_rendering) std::fprintf(stderr, "mlrt: --randomized_rendering: world from --seed=%llu, samples from seed %llu\n", (unsigned long long)seed, (unsigned long long)render_seed);
 
     bool known = false;
     for (int32_t i = 0; i < mlrt_world_count(); i++) known = known || opt["world"] == mlrt_world_name(i);
@@ -158,7 +167,7 @@ int main(int argc, char** argv) {
     params.image_height = mlrt_image_height(params.image_width, aspect_ratio);
     params.samples_per_pixel = std::atoi(opt["samples_per_pixel"].c_str());
     params.max_depth = std::atoi(opt["max_depth"].c_str());
-    params.seed = seed;
+    params.seed = render_seed;
 
     std::vector<uint8_t> earth;
     int ew = 0, eh = 0;

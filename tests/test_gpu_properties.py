@@ -144,6 +144,19 @@ def test_cli_is_a_drop_in_for_the_reference_command_line(mlrt, oracle, tmp_path)
     assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"] and chunks[0][1] == struct.pack(">IIBBBBB", 400, 266, 8, 2, 0, 0, 0)
     rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(266, 1 + 400 * 3)
     assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(266, 400, 3)[::-1].astype(np.int32), ref64)
+    # no --seed (the reference: world and samples from ThreadRng) and --randomized_rendering (samples only): seeds from the OS, printed;
+    # the printed seed reproduces the run
+    import re
+    small = [mlrt.CLI_PATH, "--world=random", "--aspect_ratio=3:2", "--image_width=120", "--samples_per_pixel=4", "--format=p6"]
+    one = subprocess.run(small, capture_output=True, check=True)
+    two = subprocess.run(small, capture_output=True, check=True)
+    assert one.stdout != two.stdout
+    printed = re.search(rb"using --seed=(\d+)", one.stderr).group(1).decode()
+    assert subprocess.run(small + ["--seed=" + printed], capture_output=True, check=True).stdout == one.stdout
+    seeded = subprocess.run(small + ["--seed=42"], capture_output=True, check=True).stdout
+    rr = subprocess.run(small + ["--seed=42", "--randomized_rendering"], capture_output=True, check=True).stdout
+    a, b = (np.frombuffer(x[len(b"P6\n120 80\n255\n"):], dtype=np.uint8).astype(np.float64) for x in (seeded, rr))
+    assert rr != seeded and np.sqrt(np.mean((a - b) ** 2)) / 255.0 < 0.25 and abs(a.mean() - b.mean()) < 4.0  # the same world, other noise
     fast = subprocess.run(args + ["--precision=fp32"], capture_output=True, check=True).stdout
     r = mlrt.Renderer(w, mlrt.default_camera(w, 1.5), mlrt.make_params(w, 400, 266, 8), precision=mlrt.PRECISION_FP32)
     assert np.array_equal(np.frombuffer(fast[len(b"P6\n400 266\n255\n"):], dtype=np.uint8).reshape(266, 400, 3)[::-1].astype(np.int32), r.render())
