@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
     bool randomized_rendering = false;
     for (int i = 1; i < argc; i++) {
         std::string a(argv[i]);
-        if (a == "--randomized_rendering" || a == "-r") { randomized_rendering = true; continue; }
+        if (a == "--randomized_rendering" || a == "-r" || a == "-rr") { randomized_rendering = true; continue; }  // clap short("rr"): -r
         if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "mlrt: unexpected argument '%s'\n", a.c_str()); return 2; }
         a = a.substr(2);
         const size_t eq = a.find('=');
