@@ -218,7 +218,8 @@ int32_t mlrt_device_count(void);
  * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*.
  * Validation happens before any device call and returns MLRT_ERR_INVALID (message in mlrt_last_error) for: no objects; a NULL
  * array with a positive count; any index out of range (materials, textures, images, Perlin tables, primitives, BVH children,
- * transforms); a BVH that is not a tree; non-finite geometry (spheres, boxes, rects, BVH bounds, transforms, medium density);
+ * transforms); a BVH that is not a tree; geometry that is not finite or of magnitude 2^100 and more (spheres, boxes, rects, BVH bounds,
+ * transform offsets; the camera of a render call likewise), a non-finite transform angle or medium density;
  * a box with min > max; rect axes other than (0,1), (0,2), (1,2); Checker textures nested deeper than 8 levels or cyclic;
  * a Perlin permutation entry outside 0..1023; unknown kinds. */
 int32_t mlrt_context_create(const mlrt_scene* scene, int32_t device, int32_t precision, mlrt_context** out); /* options from the environment */

@@ -86,15 +86,17 @@ void validate(const mlrt_scene& s) {
                      (s.n_textures == 0 || s.textures) && (s.n_images == 0 || s.images) && (s.n_perlins == 0 || s.perlins),
                  "an array with a positive element count is NULL");
     // Geometry must be finite: the reference would render NaNs, the device structure (bounds, SAH sort) cannot be built from them.
-    auto finite = [](const double* v, int n) { for (int k = 0; k < n; k++) if (!std::isfinite(v[k])) return false; return true; };
+    // ... and of a magnitude a ray tracer can work with: below 2^100 (1.3e30).  (The f64 kernels' shared-divisor quotients, mlrt_kernel.hip
+    // Divisor, are the compiler's divisions bit for bit for numerators below 2^600: products of two such lengths stay far below.)
+    auto finite = [](const double* v, int n) { for (int k = 0; k < n; k++) if (!(std::fabs(v[k]) < 0x1p100)) return false; return true; };
     auto mat_ok = [&](int32_t m) { return m >= 0 && m < s.n_materials; };
     for (int i = 0; i < s.n_spheres; i++) {
         MLRT_REQUIRE(mat_ok(s.spheres[i].material), "sphere material out of range");
-        MLRT_REQUIRE(finite(s.spheres[i].center, 3) && std::isfinite(s.spheres[i].radius), "sphere centre / radius is not finite");
+        MLRT_REQUIRE(finite(s.spheres[i].center, 3) && finite(&s.spheres[i].radius, 1), "sphere centre / radius is not finite (or is 2^100 or more)");
     }
     for (int i = 0; i < s.n_boxes; i++) {
         MLRT_REQUIRE(mat_ok(s.boxes[i].material), "box material out of range");
-        MLRT_REQUIRE(finite(s.boxes[i].min, 3) && finite(s.boxes[i].max, 3), "box corner is not finite");
+        MLRT_REQUIRE(finite(s.boxes[i].min, 3) && finite(s.boxes[i].max, 3), "box corner is not finite (or is 2^100 or more)");
         // Block::new(p0, p1) with a corner pair that is not (min, max) builds degenerate rects in the reference (AARect::new keeps
         // a1_v0 as given, aarects.rs:39 - quirk Q2 - so a side can come out with a1_v0 > a1_v1 and never be hit): not a shape
         // anyone means, and not what the device's slab form of a Block would render
@@ -105,7 +107,7 @@ void validate(const mlrt_scene& s) {
         MLRT_REQUIRE(mat_ok(r.material), "rect material out of range");
         // aarects.rs:9-17 other(): only (X,Y), (X,Z), (Y,Z) are legal, anything else panics
         MLRT_REQUIRE((r.a0 == 0 && r.a1 == 1) || (r.a0 == 0 && r.a1 == 2) || (r.a0 == 1 && r.a1 == 2), "rect axes must be (0,1), (0,2) or (1,2)");
-        MLRT_REQUIRE(std::isfinite(r.a0_v0) && std::isfinite(r.a0_v1) && std::isfinite(r.a1_v0) && std::isfinite(r.a1_v1) && std::isfinite(r.plane), "rect coordinate is not finite");
+        MLRT_REQUIRE(finite(&r.a0_v0, 1) && finite(&r.a0_v1, 1) && finite(&r.a1_v0, 1) && finite(&r.a1_v1, 1) && finite(&r.plane, 1), "rect coordinate is not finite (or is 2^100 or more)");
     }
     auto prim_ok = [&](const mlrt_prim_ref& p) {
         if (p.kind == MLRT_PRIM_SPHERE) return p.index >= 0 && p.index < s.n_spheres;
@@ -117,7 +119,7 @@ void validate(const mlrt_scene& s) {
     auto child_ok = [&](int32_t c) { return c >= 0 ? c < s.n_bvh_nodes : (~c) < s.n_prim_refs; };
     for (int i = 0; i < s.n_bvh_nodes; i++) {
         MLRT_REQUIRE(child_ok(s.bvh_nodes[i].left) && child_ok(s.bvh_nodes[i].right), "bvh child out of range");
-        MLRT_REQUIRE(finite(s.bvh_nodes[i].bounds_min, 3) && finite(s.bvh_nodes[i].bounds_max, 3), "bvh node bounds are not finite");
+        MLRT_REQUIRE(finite(s.bvh_nodes[i].bounds_min, 3) && finite(s.bvh_nodes[i].bounds_max, 3), "bvh node bounds are not finite (or are 2^100 or more)");
     }
     for (int i = 0; i < s.n_bvhs; i++) {
         MLRT_REQUIRE(s.bvhs[i].root == MLRT_BVH_EMPTY || child_ok(s.bvhs[i].root), "bvh root out of range");
@@ -773,6 +775,10 @@ void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) 
     MLRT_REQUIRE(n_rows >= 0 && n_rows <= p->image_height, "n_rows out of range");
     MLRT_REQUIRE((int64_t)n_rows * p->image_width * 3 < (int64_t)1 << 31, "frame too large: n_rows * width * 3 must stay below 2^31 (32-bit indices of the accumulation buffer)");
     MLRT_REQUIRE(p->background_kind == MLRT_BG_BLACK || p->background_kind == MLRT_BG_GRADIENT, "unknown background kind");
+    // (a camera of NaNs renders NaNs in the reference too; refused here like non-finite geometry, with the same bound on magnitudes)
+    const double* c = cam->origin;
+    static_assert(sizeof(mlrt_camera) == 19 * sizeof(double), "mlrt_camera is 19 doubles");
+    for (int k = 0; k < 19; k++) MLRT_REQUIRE(std::fabs(c[k]) < 0x1p100, "camera field is not finite (or is 2^100 or more)");
 }
 
 // One frame: candidate pre-pass (sphere-only scenes), render kernel, resolve kernel - nothing else.  The accumulation
@@ -1263,6 +1269,20 @@ int32_t mlrt_debug_probe_texture(mlrt_context* ctx, int32_t tex, int32_t n, cons
     });
 }
 // One finished sample of radiance[i] accumulated (to_fixed) and resolved with spp (to_rgb): rgb[n]
+// Divisor::over (mlrt_kernel.hip) against x / a on blocks * 256 * per_thread * 5 operand pairs made on the device; exponents of the
+// divisor / the numerators uniform in [a_lo, a_hi] / [x_lo, x_hi].  out[0] = quotients that differ, out[1..3] = bits of one x, a, q.
+int32_t mlrt_debug_probe_divide(mlrt_context* ctx, int32_t blocks, int32_t per_thread, uint32_t seed, int32_t a_lo, int32_t a_hi, int32_t x_lo, int32_t x_hi,
+                                unsigned long long out[4]) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && out && blocks >= 1 && per_thread >= 1 && a_lo <= a_hi && x_lo <= x_hi && a_lo >= -1022 && a_hi <= 1023 && x_lo >= -1022 && x_hi <= 1023, "bad argument");
+        DeviceBuffers d;
+        const unsigned long long zero[4] = {0, 0, 0, 0};
+        void* d_out = d.alloc(sizeof zero, zero);
+        const int args[6] = {per_thread, (int)seed, a_lo, a_hi, x_lo, x_hi};
+        probe_launch(ctx, 6, 0, blocks, args, nullptr, d_out, nullptr, 0, [](auto&) {});
+        MLRT_HIP(hipMemcpy(out, d_out, sizeof zero, hipMemcpyDeviceToHost));
+    });
+}
 int32_t mlrt_debug_probe_to_rgb(mlrt_context* ctx, int32_t spp, int32_t n, const double* radiance, int32_t* rgb) {
     return guarded([&] {
         MLRT_REQUIRE(ctx && radiance && rgb && n >= 0 && spp >= 1, "bad argument");

@@ -135,6 +135,48 @@ DEV float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
 DEV double sqrt_r(double x) { return sqrt(x); }
 DEV float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV double div_r(double a, double b) { return a / b; }
+// Several f64 quotients over ONE divisor (the three components of Vec3 / f64, vec.rs:184-189; the two roots of the sphere
+// quadratic over |d|^2, shapes.rs:66-73; a slab's two face distances, aarects.rs:46).  The compiler expands every x / a on
+// its own into v_div_scale_f64 x 2, v_rcp_f64, four fma (two Newton steps on the reciprocal), mul, fma, v_div_fmas_f64,
+// v_div_fixup_f64.  Everything up to the refined reciprocal depends on the divisor alone: Divisor does it once, over() is the
+// tail (mul, fma, fma) per numerator - the SAME instructions on the same values whenever v_div_scale_f64 scales nothing and
+// v_div_fixup_f64 changes nothing but the sign of a zero, i.e. for a divisor in 2^-300 .. 2^300 (checked: anything else -
+// zero, denormal, huge, NaN - divides the long way) and numerators that are zero or in 2^-600 .. 2^600 (not checked: what the
+// kernel divides are differences and products of scene coordinates and ray directions, which validate() bounds by 2^100 and the
+// materials keep above 1e-8; a quotient of zero takes its sign from x * (1/a), as v_div_fixup_f64 gives it).  So the quotient is
+// bit for bit the compiler's - which tests/test_gpu_f64_modes.py holds to the strict build (plain divisions only) over every
+// world and option, tests/test_gpu_fuzz.py to the oracle at four scales, and the probe of tests/test_gpu_directed.py to x / a
+// itself on 1e8 operand pairs.  (Range tests on every quotient were measured first: they cost what the sharing saves.)
+#ifndef MLRT_SHARED_DIVISOR
+#define MLRT_SHARED_DIVISOR 1
+#endif
+struct Divisor {
+    double a, y;
+    bool ok;
+    DEV explicit Divisor(double divisor) : a(divisor) {
+        const uint32_t exponent = ((uint32_t)__double2hiint(divisor) >> 20) & 0x7FFu;
+        ok = exponent - 723u < 600u;  // 2^-300 <= |a| < 2^300
+        double r = __builtin_amdgcn_rcp(divisor);
+        double e = __builtin_fma(-divisor, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-divisor, r, 1.0);
+        y = __builtin_fma(r, e, r);
+    }
+    DEV double tail(double x) const {
+        const double q0 = x * y;
+        const double r = __builtin_fma(-a, q0, x);
+        return __builtin_copysign(__builtin_fma(r, y, q0), q0);
+    }
+    static constexpr bool kShared = MLRT_SHARED_DIVISOR && !kStrict;
+    DEV void over(double x0, double x1, double& q0, double& q1) const {
+        if (kShared && __builtin_expect(ok, 1)) { q0 = tail(x0); q1 = tail(x1); }
+        else { q0 = x0 / a; q1 = x1 / a; }
+    }
+    DEV void over(double x0, double x1, double x2, double& q0, double& q1, double& q2) const {
+        if (kShared && __builtin_expect(ok, 1)) { q0 = tail(x0); q1 = tail(x1); q2 = tail(x2); }
+        else { q0 = x0 / a; q1 = x1 / a; q2 = x2 / a; }
+    }
+};
 DEV float min_r(float a, float b) { return fminf(a, b); }
 DEV double min_r(double a, double b) { return fmin(a, b); }
 DEV float max_r(float a, float b) { return fmaxf(a, b); }
@@ -194,7 +236,9 @@ DEV V3 unit(V3 a) {
         return a * inv;
     }
     const real len = sqrt_r(length_squared(a));
-    return mk(a.x / len, a.y / len, a.z / len);
+    double qx, qy, qz;
+    Divisor((double)len).over((double)a.x, (double)a.y, (double)a.z, qx, qy, qz);
+    return mk((real)qx, (real)qy, (real)qz);
 }
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
@@ -511,8 +555,7 @@ DEV bool sphere_roots(const SphereP& s, const Ray& r, double& near_root, double&
         far_root = (-half_b + sqrtd) * r.inv_a;
     } else {
         sqrtd = sqrt(discriminant);
-        near_root = (-half_b - sqrtd) / r.a;
-        far_root = (-half_b + sqrtd) / r.a;
+        Divisor(r.a).over(-half_b - sqrtd, -half_b + sqrtd, near_root, far_root);
     }
     return true;
 }
@@ -550,7 +593,8 @@ DEV bool box_hit_exact(const double (&b)[6], P3 o, P3 d, double tmin, double tma
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const double oa = compp(o, a), da = compp(d, a);
-        const double t0 = (b[a] - oa) / da, t1 = (b[3 + a] - oa) / da;
+        double t0, t1;
+        Divisor(da).over(b[a] - oa, b[3 + a] - oa, t0, t1);
         lo[a] = fmin(t0, t1); hi[a] = fmax(t0, t1);
     }
     return box_faces(lo, hi, tmin, tmax, t_out, axis_out);
@@ -839,7 +883,11 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
         if (kind == TAG_SPHERE) {
             const SphereP sp = sphere_params(S, c.hit_node, n);
             if (kFast) outward = to_v3(po - mkp(sp.cx, sp.cy, sp.cz)) * fast_rcp((real)sp.r);
-            else outward = mk((real)((po.x - sp.cx) / sp.r), (real)((po.y - sp.cy) / sp.r), (real)((po.z - sp.cz) / sp.r));
+            else {
+                double nx, ny, nz;
+                Divisor(sp.r).over(po.x - sp.cx, po.y - sp.cy, po.z - sp.cz, nx, ny, nz);
+                outward = mk((real)nx, (real)ny, (real)nz);
+            }
             if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) sphere_uv(outward, u, v);
         } else if ((FEAT & FEAT_BOX) && kind == TAG_BOX) {
             outward = axis_vec(c.hit_aux, (real)1);
@@ -1707,6 +1755,40 @@ __global__ void mlrt_probe_slab_kernel(int n, const DNode<creal>* boxes, const d
     r.a = 0.0; r.inv_a = 0.0;
     hit[i] = slab_hit_any(boxes[i], slab_ray(r), slab_far_bound(tmax[i])) ? 1 : 0;
 }
+// Divisor::over against the division itself on pseudo-random operand pairs made on the device: mantissas from Philox words,
+// exponents uniform in [exp_lo, exp_hi] (numerator and divisor separately), every sign, a zero numerator now and then.
+// out[0] += quotients that differ in any bit; out[1..3] = the bits of one such x, a and the shared quotient.
+__global__ void mlrt_probe_divide_kernel(int per_thread, uint32_t seed, int ax_lo, int ax_hi, int xx_lo, int xx_hi, unsigned long long* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0ull;
+    for (int k = 0; k < per_thread; k++) {
+        uint32_t w[8];
+        philox4x32_10(seed, 0x5eedu, tid, (uint32_t)k, 0u, 0u, w[0], w[1], w[2], w[3]);
+        philox4x32_10(seed, 0x5eedu, tid, (uint32_t)k, 1u, 0u, w[4], w[5], w[6], w[7]);
+        auto make = [](uint32_t lo, uint32_t hi, uint32_t e_word, int e_lo, int e_hi) {
+            const uint64_t exponent = (uint64_t)(1023 + e_lo + (int)(e_word % (uint32_t)(e_hi - e_lo + 1)));
+            const uint64_t bits = ((uint64_t)(hi >> 31) << 63) | (exponent << 52) | (((uint64_t)(hi & 0xFFFFFu) << 32) | lo);
+            return __builtin_bit_cast(double, bits);
+        };
+        const double a = make(w[0], w[1], w[2], ax_lo, ax_hi);
+        double x[3] = {make(w[3], w[4], w[5], xx_lo, xx_hi), make(w[6], w[7], w[2] >> 11, xx_lo, xx_hi), make(w[1], w[3], w[6] >> 7, xx_lo, xx_hi)};
+        if ((w[7] & 63u) == 0u) x[1] = (w[7] & 64u) ? -0.0 : 0.0;
+        if ((w[7] & 0xFC0u) == 0u) x[2] = x[0];  // (the low mantissa bits of a are often zero in practice: radii, squared lengths)
+        double q[3];
+        Divisor(a).over(x[0], x[1], x[2], q[0], q[1], q[2]);
+        for (int c = 0; c < 3; c++) {
+            const double plain = x[c] / a;
+            if (__builtin_bit_cast(uint64_t, plain) != __builtin_bit_cast(uint64_t, q[c])) {
+                bad++;
+                out[1] = __builtin_bit_cast(uint64_t, x[c]); out[2] = __builtin_bit_cast(uint64_t, a); out[3] = __builtin_bit_cast(uint64_t, q[c]);
+            }
+        }
+        double q2[2];
+        Divisor(a).over(x[2], x[0], q2[0], q2[1]);
+        if (__builtin_bit_cast(uint64_t, q2[0]) != __builtin_bit_cast(uint64_t, x[2] / a) || __builtin_bit_cast(uint64_t, q2[1]) != __builtin_bit_cast(uint64_t, x[0] / a)) bad++;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+}
 // Perlin::turbulence (textures.rs:76-88) at scale * p: the serial evaluation, and - fast build - the wave-level one of the
 // shading batch (one point per wave: 64 threads per point)
 __global__ void mlrt_probe_turbulence_kernel(const KParams<real> P, int table, int n, const double* points, double* serial, double* wave) {
@@ -1827,6 +1909,9 @@ extern "C" int MLRT_CAT(mlrt_probe_launch_, MLRT_SUFFIX)(int kind, const void* k
     else if (kind == 5) {
         hipLaunchKernelGGL(mlrt_probe_accumulate_kernel, dim3(grid), dim3(64), 0, stream, n, static_cast<const double*>(a), static_cast<unsigned long long*>(d2));
         hipLaunchKernelGGL(mlrt_resolve_kernel, dim3(grid), dim3(64), 0, stream, static_cast<unsigned long long*>(d2), n, iarg, static_cast<int32_t*>(c), static_cast<double*>(nullptr), static_cast<unsigned int*>(const_cast<void*>(b)));
+    } else if (kind == 6) {
+        const int* e = static_cast<const int*>(a);  // host pointer: per_thread, seed, divisor exponents lo / hi, numerator exponents lo / hi
+        hipLaunchKernelGGL(mlrt_probe_divide_kernel, dim3((unsigned)n), dim3(256), 0, stream, e[0], (uint32_t)e[1], e[2], e[3], e[4], e[5], static_cast<unsigned long long*>(c));
     } else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

@@ -51,6 +51,7 @@ def dbg():
     L.mlrt_debug_probe_turbulence.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mlrt_debug_probe_texture.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.mlrt_debug_probe_to_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.mlrt_debug_probe_divide.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     return m
 
 
@@ -239,4 +240,21 @@ def test_to_rgb_of_one_accumulated_sample(dbg, build):
             assert np.abs(out - e).max() <= 1 and np.array_equal(out[e == 0], e[e == 0]) and np.array_equal(out[e == 255], e[e == 255])
         else:
             assert np.array_equal(out, e), (spp, out, e)
+    m.lib().mlrt_context_destroy(ctx)
+
+
+@pytest.mark.parametrize("build", ["fp64", "fp64_cull64", "fp64_strict"])
+def test_quotients_over_a_shared_divisor_are_the_divisions(dbg, build):
+    """Divisor::over (mlrt_kernel.hip: the reciprocal refinement of x / a done once per divisor, the rest per numerator) against
+    x / a itself, bit for bit, on 2.6e8 operand pairs made on the device: inside its domain (divisors in 2^-300 .. 2^300, numerators
+    in 2^-600 .. 2^600 or zero, either sign) and with divisors OUTSIDE it (down to denormal-adjacent and up to the largest
+    exponents), which must take the division itself.  The strict build only ever divides: trivially equal."""
+    m = dbg
+    sc = dc.base(m)
+    sc.add_prim(sc.box((0, 0, 0), (1, 1, 1), sc.lambertian(sc.t_white)))
+    ctx = context(m, sc.to_ctypes(), build)
+    out = (C.c_ulonglong * 4)()
+    for seed, (a_lo, a_hi, x_lo, x_hi) in enumerate([(-300, 299, -600, 599), (-40, 40, -80, 80), (-3, 3, -8, 8), (-1022, 1023, -300, 300), (-300, 299, -300, 300)]):
+        check(m, m.lib().mlrt_debug_probe_divide(ctx, 256, 160, 1000 + seed, a_lo, a_hi, x_lo, x_hi, out))
+        assert out[0] == 0, (build, (a_lo, a_hi, x_lo, x_hi), int(out[0]), [hex(int(v)) for v in out[1:]])
     m.lib().mlrt_context_destroy(ctx)
