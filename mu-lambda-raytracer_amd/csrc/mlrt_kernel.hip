@@ -162,6 +162,9 @@ struct Divisor {
         e = __builtin_fma(-divisor, r, 1.0);
         y = __builtin_fma(r, e, r);
     }
+    // a divisor whose refined reciprocal was worked out before (the frame's width - 1 and height - 1: FrameParams)
+    DEV Divisor(double divisor, double refined_reciprocal) : a(divisor), y(refined_reciprocal), ok(true) {}
+    DEV double one(double x) const { return kShared ? tail(x) : x / a; }
     DEV double tail(double x) const {
         const double q0 = x * y;
         const double r = __builtin_fma(-a, q0, x);
@@ -1005,6 +1008,11 @@ DEV V3 background_color(const KParams<real>& P, const FrameParams& F, P3 d) {  /
 // evaluates the lens offset's sin/cos in f32).  A fresh sample's four draws - u, v and the lens sample, drawn by
 // inverse CDF from two words (r = sqrt(u1'), phi = 2*pi*u2; the reference's rejection loop is vec.rs:45-52, quirk Q6:
 // the draws are consumed even when lens_radius == 0) - are exactly Philox block 0: no loop, no refill branch.
+// f64 builds: F.inv_wm1 / F.inv_hm1 become the device's own refined reciprocals of width - 1 and height - 1 (Divisor), not the host's
+// 1 / x: gen_camera_ray divides by them with the tail of the compiler's division sequence.  Called by the threads that filled F.
+DEV void frame_reciprocals(const KParams<real>& P, FrameParams& F) {
+    if (!kFast && threadIdx.x < 2) (&F.inv_wm1)[threadIdx.x] = Divisor((double)(threadIdx.x == 0 ? P.width : P.height) - 1.0).y;
+}
 DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, RngKey key, int i, int j, P3& o, P3& d) {
     uint32_t b0, b1, b2, b3;
     philox4x32_10(key.k0, key.k1, 0u, g.sample, g.pixel, 0u, b0, b1, b2, b3);
@@ -1032,8 +1040,10 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
         return;
     }
     // (fast build: times the reciprocal - an f64 division is ~25 instructions, twice per sample)
-    const double s = kFast ? ((double)i + u01d(b0)) * F.inv_wm1 : ((double)i + u01d(b0)) / ((double)P.width - 1.0);
-    const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : ((double)j + u01d(b1)) / ((double)P.height - 1.0);
+    // f64 builds: the division of raytrace.rs:191-192 over the frame's two constant divisors (1 .. 2^31: always inside Divisor's domain),
+    // whose refined reciprocals frame_reciprocals() left in F
+    const double s = kFast ? ((double)i + u01d(b0)) * F.inv_wm1 : Divisor((double)P.width - 1.0, F.inv_wm1).one((double)i + u01d(b0));
+    const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : Divisor((double)P.height - 1.0, F.inv_hm1).one((double)j + u01d(b1));
     const P3 origin = ld3p(F.cam_origin);
     const P3 through = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin;
     if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is: nothing to add
@@ -1256,6 +1266,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     }
     FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytesPerWave);
     if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... inv_hm1 are contiguous in both structs
+    frame_reciprocals(P, F);
     if (threadIdx.x < 3) {
         F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x];
         F.through0[threadIdx.x] = (float)(P.cam_llc[threadIdx.x] - P.cam_origin[threadIdx.x]);
@@ -1729,6 +1740,7 @@ __global__ void mlrt_probe_rays_kernel(const KParams<real> P, int n, const doubl
 __global__ void mlrt_probe_camera_kernel(const KParams<real> P, int n, const int32_t* ijs, double* out) {
     __shared__ FrameParams F;
     if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];
+    frame_reciprocals(P, F);
     if (threadIdx.x < 3) {
         F.bg_top[threadIdx.x] = P.bg_top[threadIdx.x]; F.bg_bottom[threadIdx.x] = P.bg_bottom[threadIdx.x];
         F.through0[threadIdx.x] = (float)(P.cam_llc[threadIdx.x] - P.cam_origin[threadIdx.x]);
