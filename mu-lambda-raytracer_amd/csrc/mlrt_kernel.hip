@@ -307,6 +307,89 @@ DEV real u01(uint32_t w) { return (real)(w >> 8) * (real)(1.0 / 16777216.0); }
 DEV double u01d(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
 // rand's UniformFloat::sample_single: u * (high - low) + low (the >= high retry cannot trigger for 24-bit u)
 DEV real sym(uint32_t w) { return u01(w) * (real)2 + (real)-1; }  // gen_range(-1.0..1.0)
+// cos and sin of 2 pi k / 2^24 for the 24-bit k of a sampler's uniform (unit_ball_from_words, the lens disk of gen_camera_ray): part of
+// the DEVICE CONTRACT, defined as arithmetic - not "whatever libm returns" - so that the oracle (oracle_core.hpp turn_cos_sin, the same
+// lines with std::fma) gets the very same doubles: the nearest of 64 tabulated angles (sin, cos exact at the axes and diagonals), then
+// the Taylor polynomials of the remainder |x| <= pi / 64 (next terms 5e-18 and 2e-20) and the angle-sum formulas, every operation
+// an exactly rounded mul or fma.  |error| < 3e-16; 15 f64 instructions where ocml's sincospi takes 29 plus as many integer ones.
+__device__ const double kTurnTable[64][2] = {
+    {0x0.0p+0, 0x1.0000000000000p+0},
+    {0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1},
+    {0x1.8f8b83c69a60ap-3, 0x1.f6297cff75cb0p-1},
+    {0x1.294062ed59f05p-2, 0x1.e9f4156c62ddap-1},
+    {0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1},
+    {0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1},
+    {0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},
+    {0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1},
+    {0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},
+    {0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1},
+    {0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c9p-1},
+    {0x1.c38b2f180bdb0p-1, 0x1.e2b5d3806f63ep-2},
+    {0x1.d906bcf328d46p-1, 0x1.87de2a6aea964p-2},
+    {0x1.e9f4156c62ddbp-1, 0x1.294062ed59f05p-2},
+    {0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60dp-3},
+    {0x1.fd88da3d12525p-1, 0x1.917a6bc29b438p-4},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.fd88da3d12526p-1, -0x1.917a6bc29b42fp-4},
+    {0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a608p-3},
+    {0x1.e9f4156c62ddbp-1, -0x1.294062ed59f02p-2},
+    {0x1.d906bcf328d46p-1, -0x1.87de2a6aea962p-2},
+    {0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63cp-2},
+    {0x1.a9b66290ea1a5p-1, -0x1.1c73b39ae68c6p-1},
+    {0x1.8bc806b151742p-1, -0x1.44cf325091dd5p-1},
+    {0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1},
+    {0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1},
+    {0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a4p-1},
+    {0x1.e2b5d3806f63fp-2, -0x1.c38b2f180bdb0p-1},
+    {0x1.87de2a6aea965p-2, -0x1.d906bcf328d46p-1},
+    {0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1},
+    {0x1.8f8b83c69a617p-3, -0x1.f6297cff75cb0p-1},
+    {0x1.917a6bc29b43cp-4, -0x1.fd88da3d12525p-1},
+    {0x0.0p+0, -0x1.0000000000000p+0},
+    {-0x1.917a6bc29b42bp-4, -0x1.fd88da3d12526p-1},
+    {-0x1.8f8b83c69a60ep-3, -0x1.f6297cff75cb0p-1},
+    {-0x1.294062ed59f01p-2, -0x1.e9f4156c62ddbp-1},
+    {-0x1.87de2a6aea961p-2, -0x1.d906bcf328d47p-1},
+    {-0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1},
+    {-0x1.1c73b39ae68c6p-1, -0x1.a9b66290ea1a5p-1},
+    {-0x1.44cf325091dd4p-1, -0x1.8bc806b151742p-1},
+    {-0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1},
+    {-0x1.8bc806b15173ep-1, -0x1.44cf325091ddap-1},
+    {-0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1},
+    {-0x1.c38b2f180bdb0p-1, -0x1.e2b5d3806f63fp-2},
+    {-0x1.d906bcf328d44p-1, -0x1.87de2a6aea96dp-2},
+    {-0x1.e9f4156c62ddap-1, -0x1.294062ed59f07p-2},
+    {-0x1.f6297cff75cafp-1, -0x1.8f8b83c69a619p-3},
+    {-0x1.fd88da3d12526p-1, -0x1.917a6bc29b421p-4},
+    {-0x1.0000000000000p+0, 0x0.0p+0},
+    {-0x1.fd88da3d12526p-1, 0x1.917a6bc29b407p-4},
+    {-0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60cp-3},
+    {-0x1.e9f4156c62ddbp-1, 0x1.294062ed59f00p-2},
+    {-0x1.d906bcf328d45p-1, 0x1.87de2a6aea967p-2},
+    {-0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63ap-2},
+    {-0x1.a9b66290ea1a5p-1, 0x1.1c73b39ae68c5p-1},
+    {-0x1.8bc806b151740p-1, 0x1.44cf325091dd7p-1},
+    {-0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},
+    {-0x1.44cf325091ddap-1, 0x1.8bc806b15173ep-1},
+    {-0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},
+    {-0x1.e2b5d3806f640p-2, 0x1.c38b2f180bdafp-1},
+    {-0x1.87de2a6aea96ep-2, 0x1.d906bcf328d44p-1},
+    {-0x1.294062ed59f08p-2, 0x1.e9f4156c62ddap-1},
+    {-0x1.8f8b83c69a61bp-3, 0x1.f6297cff75cafp-1},
+    {-0x1.917a6bc29b425p-4, 0x1.fd88da3d12526p-1}
+};
+DEV void turn_cos_sin(uint32_t k, double& cs, double& sn) {
+    const uint32_t j = (k + (1u << 17)) >> 18;
+    const int dk = (int)k - (int)(j << 18);
+    const double x = (double)dk * 0x1.921fb54442d18p-22;  // 2 pi / 2^24
+    const double x2 = x * x;
+    const double ps = __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, -0x1.a01a01a01a01ap-13, 0x1.1111111111111p-7), -0x1.5555555555555p-3), 1.0);
+    const double sx = x * ps;
+    const double cx = __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, 0x1.a01a01a01a01ap-16, -0x1.6c16c16c16c17p-10), 0x1.5555555555555p-5), -0.5), 1.0);
+    const double ta_sin = kTurnTable[j & 63u][0], ta_cos = kTurnTable[j & 63u][1];
+    sn = __builtin_fma(ta_sin, cx, ta_cos * sx);
+    cs = __builtin_fma(ta_cos, cx, -(ta_sin * sx));
+}
 // Uniform point in the unit ball.  The reference draws it by rejection (vec.rs:23-30); the device contract (and the
 // oracle's Philox mode, oracle/oracle.cpp closed_form_unit_sphere) draws the same distribution by inverse CDF from
 // exactly three words - z = 2*u1 - 1, phi = 2*pi*u2, r = cbrt((w3>>8 + 1) * 2^-24) - so there is no data-dependent
@@ -323,13 +406,9 @@ DEV V3 unit_ball_from_words(uint32_t w0, uint32_t w1, uint32_t w2) {
         return mk((real)(rs * __builtin_amdgcn_cosf(turn)), (real)(rs * __builtin_amdgcn_sinf(turn)), (real)(r * z));
     }
     const double z = u01d(w0) * 2.0 + -1.0;
-    const double turn = u01d(w1);
     const double r = cbrt(((double)(w2 >> 8) + 1.0) * (1.0 / 16777216.0));
-    // cos / sin of phi = 2 pi turn, turn = k 2^-24 exact: sincospi reduces the argument exactly and needs none of libm's large-
-    // argument machinery (C2 f64 62.0 -> 58.9 ms).  The oracle evaluates cos(2.0 * PI * turn) with glibc: the same function to
-    // ~1e-16, inside the f64 parity tolerance; all device f64 builds share this code, so their colour sums stay bit-equal.
     double sn_phi, cs_phi;
-    sincospi(2.0 * turn, &sn_phi, &cs_phi);
+    turn_cos_sin(w1 >> 8, cs_phi, sn_phi);  // phi = 2 pi (w1 >> 8) 2^-24
     const double sn = sqrt(fmax(0.0, 1.0 - z * z));
     const double rs = r * sn;
     return mk((real)(rs * cs_phi), (real)(rs * sn_phi), (real)(r * z));
@@ -1048,10 +1127,9 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
     const P3 through = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin;
     if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is: nothing to add
         const double u1 = ((double)(b2 >> 8) + 1.0) * (1.0 / 16777216.0);
-        const double turn = u01d(b3);
         double cs, sn;
-        if (kFast) { cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
-        else { sincospi(2.0 * turn, &sn, &cs); }  // (see unit_ball_from_words)
+        if (kFast) { const double turn = u01d(b3); cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
+        else turn_cos_sin(b3 >> 8, cs, sn);
         const double r = sqrt(u1);
         const double rdx = F.lens_radius * (r * cs);
         const double rdy = F.lens_radius * (r * sn);

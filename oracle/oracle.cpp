@@ -14,18 +14,20 @@ thread_local Stats g_stats;
 Vec3 closed_form_unit_sphere(Rng& rng) {
     PhiloxStream& ps = static_cast<PhiloxStream&>(rng);
     const double z = ps.uniform01() * 2.0 + -1.0;
-    const double turn = ps.uniform01();
+    const uint32_t k = ps.uniform_24_bits();  // phi = 2 pi k 2^-24
     const double r = std::cbrt(ps.uniform_0_1_closed_top());
-    const double phi = 2.0 * PI * turn;
+    double cs_phi, sn_phi;
+    turn_cos_sin(k, cs_phi, sn_phi);
     const double s = std::sqrt(std::fmax(0.0, 1.0 - z * z));
     const double rs = r * s;
-    return Vec3(rs * std::cos(phi), rs * std::sin(phi), r * z);
+    return Vec3(rs * cs_phi, rs * sn_phi, r * z);
 }
 Vec3 closed_form_unit_disk(Rng& rng) {
     PhiloxStream& ps = static_cast<PhiloxStream&>(rng);
     const double r = std::sqrt(ps.uniform_0_1_closed_top());
-    const double phi = 2.0 * PI * ps.uniform01();
-    return Vec3(r * std::cos(phi), r * std::sin(phi), 0.0);
+    double cs_phi, sn_phi;
+    turn_cos_sin(ps.uniform_24_bits(), cs_phi, sn_phi);
+    return Vec3(r * cs_phi, r * sn_phi, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -237,6 +237,10 @@ struct PhiloxStream : Rng {
         g_stats.draws++;
         return (double)(next_u32() >> 8) * (1.0 / 16777216.0);
     }
+    uint32_t uniform_24_bits() {  // the k of uniform01() = k 2^-24 (the samplers' angle: turn_cos_sin)
+        g_stats.draws++;
+        return next_u32() >> 8;
+    }
 };
 
 // vec.rs:15-52 random helpers.  Rust evaluates call arguments left to right: x, then y, then z.
@@ -250,6 +254,87 @@ inline Vec3 vec3_random(double lo, double hi, Rng& rng) {  // vec.rs:15-17
 // z = 2*u1 - 1, phi = 2*pi*u2, r = cbrt(u3') - the same distribution as the reference's rejection loop, which stays
 // in force for the Pcg64 mode (tests/test_oracle_samplers.py checks the two statistically and at image level).
 struct PhiloxStream;
+// cos and sin of 2 pi k / 2^24 for the 24-bit k of a sampler's uniform: the device contract defines them as THIS arithmetic (mlrt_kernel.hip
+// turn_cos_sin, the same lines): the nearest of 64 tabulated angles, Taylor polynomials of the remainder |x| <= pi / 64, angle-sum
+// formulas; every operation an exactly rounded mul or fma, so oracle and device get the very same doubles.  |error| < 3e-16.
+inline void turn_cos_sin(uint32_t k, double& cs, double& sn) {
+    static const double kTurnTable[64][2] = {
+        {0x0.0p+0, 0x1.0000000000000p+0},
+        {0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1},
+        {0x1.8f8b83c69a60ap-3, 0x1.f6297cff75cb0p-1},
+        {0x1.294062ed59f05p-2, 0x1.e9f4156c62ddap-1},
+        {0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1},
+        {0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1},
+        {0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},
+        {0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1},
+        {0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},
+        {0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1},
+        {0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c9p-1},
+        {0x1.c38b2f180bdb0p-1, 0x1.e2b5d3806f63ep-2},
+        {0x1.d906bcf328d46p-1, 0x1.87de2a6aea964p-2},
+        {0x1.e9f4156c62ddbp-1, 0x1.294062ed59f05p-2},
+        {0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60dp-3},
+        {0x1.fd88da3d12525p-1, 0x1.917a6bc29b438p-4},
+        {0x1.0000000000000p+0, 0x0.0p+0},
+        {0x1.fd88da3d12526p-1, -0x1.917a6bc29b42fp-4},
+        {0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a608p-3},
+        {0x1.e9f4156c62ddbp-1, -0x1.294062ed59f02p-2},
+        {0x1.d906bcf328d46p-1, -0x1.87de2a6aea962p-2},
+        {0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63cp-2},
+        {0x1.a9b66290ea1a5p-1, -0x1.1c73b39ae68c6p-1},
+        {0x1.8bc806b151742p-1, -0x1.44cf325091dd5p-1},
+        {0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1},
+        {0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1},
+        {0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a4p-1},
+        {0x1.e2b5d3806f63fp-2, -0x1.c38b2f180bdb0p-1},
+        {0x1.87de2a6aea965p-2, -0x1.d906bcf328d46p-1},
+        {0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1},
+        {0x1.8f8b83c69a617p-3, -0x1.f6297cff75cb0p-1},
+        {0x1.917a6bc29b43cp-4, -0x1.fd88da3d12525p-1},
+        {0x0.0p+0, -0x1.0000000000000p+0},
+        {-0x1.917a6bc29b42bp-4, -0x1.fd88da3d12526p-1},
+        {-0x1.8f8b83c69a60ep-3, -0x1.f6297cff75cb0p-1},
+        {-0x1.294062ed59f01p-2, -0x1.e9f4156c62ddbp-1},
+        {-0x1.87de2a6aea961p-2, -0x1.d906bcf328d47p-1},
+        {-0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1},
+        {-0x1.1c73b39ae68c6p-1, -0x1.a9b66290ea1a5p-1},
+        {-0x1.44cf325091dd4p-1, -0x1.8bc806b151742p-1},
+        {-0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1},
+        {-0x1.8bc806b15173ep-1, -0x1.44cf325091ddap-1},
+        {-0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1},
+        {-0x1.c38b2f180bdb0p-1, -0x1.e2b5d3806f63fp-2},
+        {-0x1.d906bcf328d44p-1, -0x1.87de2a6aea96dp-2},
+        {-0x1.e9f4156c62ddap-1, -0x1.294062ed59f07p-2},
+        {-0x1.f6297cff75cafp-1, -0x1.8f8b83c69a619p-3},
+        {-0x1.fd88da3d12526p-1, -0x1.917a6bc29b421p-4},
+        {-0x1.0000000000000p+0, 0x0.0p+0},
+        {-0x1.fd88da3d12526p-1, 0x1.917a6bc29b407p-4},
+        {-0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60cp-3},
+        {-0x1.e9f4156c62ddbp-1, 0x1.294062ed59f00p-2},
+        {-0x1.d906bcf328d45p-1, 0x1.87de2a6aea967p-2},
+        {-0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63ap-2},
+        {-0x1.a9b66290ea1a5p-1, 0x1.1c73b39ae68c5p-1},
+        {-0x1.8bc806b151740p-1, 0x1.44cf325091dd7p-1},
+        {-0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},
+        {-0x1.44cf325091ddap-1, 0x1.8bc806b15173ep-1},
+        {-0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},
+        {-0x1.e2b5d3806f640p-2, 0x1.c38b2f180bdafp-1},
+        {-0x1.87de2a6aea96ep-2, 0x1.d906bcf328d44p-1},
+        {-0x1.294062ed59f08p-2, 0x1.e9f4156c62ddap-1},
+        {-0x1.8f8b83c69a61bp-3, 0x1.f6297cff75cafp-1},
+        {-0x1.917a6bc29b425p-4, 0x1.fd88da3d12526p-1}
+    };
+    const uint32_t j = (k + (1u << 17)) >> 18;
+    const int dk = (int)k - (int)(j << 18);
+    const double x = (double)dk * 0x1.921fb54442d18p-22;  // 2 pi / 2^24
+    const double x2 = x * x;
+    const double ps = std::fma(x2, std::fma(x2, std::fma(x2, -0x1.a01a01a01a01ap-13, 0x1.1111111111111p-7), -0x1.5555555555555p-3), 1.0);
+    const double sx = x * ps;
+    const double cx = std::fma(x2, std::fma(x2, std::fma(x2, std::fma(x2, 0x1.a01a01a01a01ap-16, -0x1.6c16c16c16c17p-10), 0x1.5555555555555p-5), -0.5), 1.0);
+    const double ta_sin = kTurnTable[j & 63u][0], ta_cos = kTurnTable[j & 63u][1];
+    sn = std::fma(ta_sin, cx, ta_cos * sx);
+    cs = std::fma(ta_cos, cx, -(ta_sin * sx));
+}
 Vec3 closed_form_unit_sphere(Rng& rng);
 Vec3 closed_form_unit_disk(Rng& rng);
 inline Vec3 random_in_unit_sphere(Rng& rng) {  // vec.rs:23-30
