@@ -15,7 +15,7 @@ Vec3 closed_form_unit_sphere(Rng& rng) {
     PhiloxStream& ps = static_cast<PhiloxStream&>(rng);
     const double z = ps.uniform01() * 2.0 + -1.0;
     const uint32_t k = ps.uniform_24_bits();  // phi = 2 pi k 2^-24
-    const double r = std::cbrt(ps.uniform_0_1_closed_top());
+    const double r = cbrt24(ps.uniform_24_bits() + 1u);
     double cs_phi, sn_phi;
     turn_cos_sin(k, cs_phi, sn_phi);
     const double s = std::sqrt(std::fmax(0.0, 1.0 - z * z));

@@ -335,6 +335,27 @@ inline void turn_cos_sin(uint32_t k, double& cs, double& sn) {
     sn = std::fma(ta_sin, cx, ta_cos * sx);
     cs = std::fma(ta_cos, cx, -(ta_sin * sx));
 }
+// cbrt(n 2^-24), n = 1 .. 2^24: the radius of the contract's unit-ball sample, defined as this arithmetic (mlrt_kernel.hip cbrt24, the
+// same lines): relative error <= 5.5e-16 over all inputs, exact at both ends.
+inline double cbrt24(uint32_t n) {
+    const int e = 31 - __builtin_clz(n);
+    double f = (double)n;
+    uint64_t b;
+    std::memcpy(&b, &f, 8); b -= (uint64_t)e << 52; std::memcpy(&f, &b, 8);  // n 2^-e in [1, 2)
+    const int q3 = (e * 11) >> 5;  // e / 3 for e <= 24
+    const int rem = e - 3 * q3;
+    double z = std::fma(f, std::fma(f, std::fma(f, -0x1.9239a09c3fa5fp-5, 0x1.407a7b055bc3ep-2), -0x1.9a4cbd01c7c23p-1), 0x1.897a11517ead3p+0);
+    for (int it = 0; it < 2; it++) {
+        const double z2 = z * z;
+        const double h = std::fma(-f * z2, z, 1.0);
+        const double p = std::fma(h, 0x1.c71c71c71c71cp-3, 0x1.5555555555555p-2);
+        z = std::fma(z * h, p, z);
+    }
+    double y = f * z * z;
+    y *= rem == 0 ? 1.0 : (rem == 1 ? 0x1.428a2f98d728bp+0 : 0x1.965fea53d6e3dp+0);  // cbrt(2), cbrt(4)
+    std::memcpy(&b, &y, 8); b += (uint64_t)(int64_t)(q3 - 8) << 52; std::memcpy(&y, &b, 8);  // 2^(q - 8)
+    return y;
+}
 Vec3 closed_form_unit_sphere(Rng& rng);
 Vec3 closed_form_unit_disk(Rng& rng);
 inline Vec3 random_in_unit_sphere(Rng& rng) {  // vec.rs:23-30

@@ -3,8 +3,11 @@ the SAME Philox streams (oracle[Philox] vs GPU[Philox], sample for sample) on se
 seconds.
 
 Tolerances (stated, per SURVEY.md 7 "parity ladder"):
- * fp64 parity build: the 8-bit image must EQUAL the oracle's except for at most 0.01% of channels (libm last-ulp
-   differences in tan/sin/log/acos/atan2 and the iterative-vs-recursive throughput product can flip a rounding).
+ * fp64 parity build: the 8-bit image must EQUAL the oracle's.  Where no libm function is on the device path - the `random`,
+   `simple` and `cornell_box` worlds, i.e. BASELINE configs[1] and [2]: sqrt and division are IEEE-exact on both sides and the
+   samplers' cos / sin / cbrt are arithmetic of the contract (turn_cos_sin, cbrt24: the same mul / fma sequence in oracle and
+   device) - not one channel may differ.  Elsewhere (sin in Checker / Noise textures, log in media, acos / atan2 in sphere_uv)
+   device libm and glibc differ in the last ulp, which a deep path can amplify: at most 0.01 % of the channels.
  * fp32 fast build: per-channel RMSE < 1e-3 in [0,1] units of the 8-bit gamma-space image (BASELINE.json north_star),
    the differences being f32 rounding that flips rare accept/reject and hit/miss decisions.  Those flips are unbiased
    and independent per sample, so the RMSE falls like 1/sqrt(spp): on `random` it is ~1e-4 at every spp tested; on
@@ -52,11 +55,14 @@ SMALL = [  # world, width, aspect, spp
     ("debug_perlin", 160, 1.0, 16), ("final_scene", 200, 1.0, 16)]
 
 
+LIBM_FREE = {"simple", "random", "cornell_box"}  # no sin / log / acos / atan2 on the device path of these worlds
+
+
 @pytest.mark.parametrize("name,width,aspect,spp", SMALL)
 def test_fp64_build_equals_oracle(mlrt, oracle, earthmap, name, width, aspect, spp):
     got, ref, info = render_both(mlrt, oracle, name, width, aspect, spp, mlrt.PRECISION_FP64, earth=earthmap if name in ("earth", "final_scene") else None)
     frac, rmse, maxdiff = metrics(got, ref)
-    assert frac <= 1e-4, (frac, rmse, maxdiff)
+    assert frac <= (0.0 if name in LIBM_FREE else 1e-4), (frac, rmse, maxdiff)
 
 
 @pytest.mark.parametrize("name,width,aspect,spp", SMALL)
@@ -77,7 +83,7 @@ def test_baseline_config1_full_image(mlrt, oracle):
     """BASELINE.json configs[0]: --world=random --seed=42 --aspect_ratio=3:2 --image_width=400 --samples_per_pixel=8."""
     got, ref, _ = render_both(mlrt, oracle, "random", 400, 1.5, 8, mlrt.PRECISION_FP64)
     assert got.shape == (266, 400, 3)  # quirk Q13: 400 @ 3:2 -> 266 rows
-    assert metrics(got, ref)[0] <= 1e-4
+    assert np.array_equal(got, ref)  # (a libm-free path: exact)
     got32, _, _ = render_both(mlrt, oracle, "random", 400, 1.5, 8, mlrt.PRECISION_FP32)
     assert metrics(got32, ref)[1] < 1e-3
 
@@ -85,7 +91,7 @@ def test_baseline_config1_full_image(mlrt, oracle):
 def test_defocus_blur_ray_generation(mlrt, oracle):
     """BASELINE.json configs[2]: --aperture=0.1 --focus_dist=10.0 (thin-lens sampling, camera.rs:40-48)."""
     got, ref, _ = render_both(mlrt, oracle, "random", 400, 1.5, 8, mlrt.PRECISION_FP64, aperture=0.1, focus=10.0)
-    assert metrics(got, ref)[0] <= 1e-4
+    assert np.array_equal(got, ref)
     plain, _, _ = render_both(mlrt, oracle, "random", 400, 1.5, 8, mlrt.PRECISION_FP64)
     assert metrics(got, plain)[1] > 0.01  # the lens changes the picture
 
@@ -97,7 +103,7 @@ def test_baseline_config2_rows_at_full_size(mlrt, oracle, precision_name):
     got, ref, _ = render_both(mlrt, oracle, "random", 1200, 1.5, 500, precision, rows=[40, 480, 700])
     frac, rmse, maxdiff = metrics(got, ref)
     if precision_name == "fp64":
-        assert frac <= 1e-4, (frac, rmse, maxdiff)
+        assert frac == 0.0, (frac, rmse, maxdiff)  # (a libm-free path: see the module docstring)
     else:
         assert rmse < 1e-3 and maxdiff <= 3, (frac, rmse, maxdiff)
 
@@ -110,7 +116,7 @@ def test_baseline_config3_rows_at_full_size(mlrt, oracle, precision_name):
     got, ref, _ = render_both(mlrt, oracle, "random", 1200, 1.5, 500, precision, rows=[60, 400, 640], aperture=0.1, focus=10.0)
     frac, rmse, maxdiff = metrics(got, ref)
     if precision_name == "fp64":
-        assert frac <= 1e-4, (frac, rmse, maxdiff)
+        assert frac == 0.0, (frac, rmse, maxdiff)
     else:
         assert rmse < 1e-3 and maxdiff <= 3, (frac, rmse, maxdiff)
 
@@ -142,8 +148,8 @@ def test_edge_cases(mlrt, oracle):
     got, ref, _ = render_both(mlrt, oracle, "random", 100, 1.5, 4, mlrt.PRECISION_FP64, max_depth=0)
     assert not got.any() and not ref.any()
     got, ref, _ = render_both(mlrt, oracle, "random", 100, 1.5, 4, mlrt.PRECISION_FP64, max_depth=1)
-    assert metrics(got, ref)[0] <= 1e-4
+    assert np.array_equal(got, ref)
     got, ref, _ = render_both(mlrt, oracle, "random", 131, 1.5, 3, mlrt.PRECISION_FP64, seed=7)
     assert got.shape[1] == 131 and metrics(got, ref)[0] <= 1e-4
     got, ref, _ = render_both(mlrt, oracle, "random", 64, 1.0, 5000, mlrt.PRECISION_FP64, rows=[31])  # spp > tile queue granularity
-    assert metrics(got, ref)[0] <= 1e-4
+    assert np.array_equal(got, ref)
