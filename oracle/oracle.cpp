@@ -386,6 +386,26 @@ void orc_philox_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, int n, d
 }
 
 // n samples of the unit-ball / unit-disk samplers: mode 0 = reference rejection on Pcg64(seed), 1 = device contract on Philox(seed, pixel 0, sample i)
+// The contract's own transcendental arithmetic against long-double libm over ALL 2^24 inputs: out = max relative error of cbrt24,
+// max absolute errors of turn_cos_sin's cos and sin, and the sampler values at the ends (cbrt24(1), cbrt24(2^24), cos / sin of k = 0, 2^22).
+void orc_contract_function_errors(double out[10]) {
+    long double worst_cbrt = 0.0L, worst_cos = 0.0L, worst_sin = 0.0L;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (uint32_t n = 1; n <= (1u << 24); n++) {
+        const long double t = cbrtl((long double)n / 16777216.0L);
+        worst_cbrt = std::fmax(worst_cbrt, fabsl(((long double)cbrt24(n) - t) / t));
+        double cs, sn;
+        turn_cos_sin(n - 1u, cs, sn);
+        const long double a = two_pi * (long double)(n - 1u) / 16777216.0L;
+        worst_cos = std::fmax(worst_cos, fabsl((long double)cs - cosl(a)));
+        worst_sin = std::fmax(worst_sin, fabsl((long double)sn - sinl(a)));
+    }
+    out[0] = (double)worst_cbrt; out[1] = (double)worst_cos; out[2] = (double)worst_sin;
+    out[3] = cbrt24(1u); out[4] = cbrt24(1u << 24);
+    turn_cos_sin(0u, out[5], out[6]);
+    turn_cos_sin(1u << 22, out[7], out[8]);  // a quarter turn
+    out[9] = 0.0;
+}
 void orc_sample_ball(uint64_t seed, int mode, int n, double* out) {
     if (mode == 0) { Pcg64 g = Pcg64::seed_from_u64(seed); for (int i = 0; i < n; i++) { Vec3 p = random_in_unit_sphere(g); out[3 * i] = p.e[0]; out[3 * i + 1] = p.e[1]; out[3 * i + 2] = p.e[2]; } }
     else for (int i = 0; i < n; i++) { PhiloxStream g(seed, 0, (uint32_t)i); Vec3 p = random_in_unit_sphere(g); out[3 * i] = p.e[0]; out[3 * i + 1] = p.e[1]; out[3 * i + 2] = p.e[2]; }

@@ -83,3 +83,15 @@ def test_device_contract_renders_the_same_picture_as_the_reference_algorithm(ora
     assert diff < 1.35 * noise, (name, diff, noise)
     assert abs(dev.mean() / pcg_a.mean() - 1.0) < (0.01 if name == "random" else 0.03), (name, dev.mean() / pcg_a.mean())
     w.close()
+
+
+def test_contract_arithmetic_of_the_samplers_is_accurate_over_all_inputs(oracle):
+    """cbrt24 and turn_cos_sin (oracle_core.hpp; the same lines in mlrt_kernel.hip) ARE the contract's cube root and cos / sin of a
+    24-bit draw - defined as mul / fma sequences so that oracle and device agree to the bit.  Here: all 2^24 inputs of each
+    against long-double libm, and exact values at the ends and on the axes."""
+    out = (C.c_double * 10)()
+    oracle.L.orc_contract_function_errors(out)
+    assert out[0] < 6e-16, out[0]                      # cbrt24: relative
+    assert out[1] < 8e-16 and out[2] < 8e-16, (out[1], out[2])   # cos, sin: absolute (measured 6.4e-16, 6.9e-16)
+    assert out[3] == 2.0 ** -8 and out[4] == 1.0       # cbrt(2^-24), cbrt(1)
+    assert (out[5], out[6]) == (1.0, 0.0) and (out[7], out[8]) == (0.0, 1.0)
