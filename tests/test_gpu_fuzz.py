@@ -159,8 +159,9 @@ def test_random_scenes_one_bounce_against_the_oracle(dbg, oracle, build, place):
 # ======================================================================================================================
 # Whole frames of random scenes: the megakernel itself (lane state machine, batches, tile queue, candidate lists, media
 # sequences, depth limit, accumulation, to_rgb) through the C ABI of the RELEASE library against the oracle's render of the
-# same flattened scene with the same Philox streams.  Criteria as tests/test_gpu_parity.py: f64 8-bit image equal but for
-# <= 0.05 % of the channels (libm last-ulp differences; small frames: one flipped sample is a visible share), fast build RMSE.
+# same flattened scene with the same Philox streams.  Criteria as tests/test_gpu_parity.py: f64 8-bit image equal - exactly for the
+# sphere-only scenes, whose device path calls no libm function; <= 0.05 % of the channels where sin / log / acos / atan2 are in play
+# (small frames: one flipped sample is a visible share) -, fast build by RMSE.
 def cam19(c):
     return list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v) + [c.lens_radius]
 
@@ -271,7 +272,7 @@ def test_random_sphere_scenes_whole_frames(mlrt, oracle, precision_name):
         frac, rmse = diff(got, ref)
         assert lds == 1 or len(sc.spheres) > 1000  # (1500 spheres with f64 payload slots: read from HBM / L2)
         if precision_name == "fp64":
-            assert frac <= 5e-4, (seed, frac, rmse)
+            assert frac == 0.0, (seed, frac, rmse)  # sphere-only scenes: no libm call on the device path, the frame is the oracle's
         else:
             assert rmse <= 1e-3, (seed, frac, rmse)
         if seed % 2 == 0:
