@@ -26,7 +26,8 @@
     int mlrt_acc_bytes_per_wave_##sfx(void);                                                                                       \
     int mlrt_lds_frame_bytes_##sfx(void);                                                                                          \
     int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);                                                          \
-    int mlrt_perlin_in_hbm_##sfx(void);
+    int mlrt_perlin_in_hbm_##sfx(void);                                                                                           \
+    int mlrt_lean_materials_in_hbm_##sfx(void);
 extern "C" {
 MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
@@ -58,13 +59,14 @@ struct KernelBuild {
     int (*occupancy)(int, int, size_t);
     int (*probe)(int, const void*, int, const void*, const void*, void*, void*, int, hipStream_t);  // debug library only, else nullptr
     int (*perlin_in_hbm)(void);
+    int (*lean_materials_in_hbm)(void);
 };
 #ifdef MLRT_DEBUG_BUILD
 #define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
 #else
 #define MLRT_PROBE_OF(sfx) nullptr
 #endif
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx}
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -1009,6 +1011,7 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
         // (f64 builds read the Perlin tables - the blob's tail - from HBM: they alone would keep final_scene's blob out of LDS)
         c->lds_blob_bytes = c->build->perlin_in_hbm() ? c->off[3] : (int32_t)blob.size();
+        if (c->variant == 1 && c->build->lean_materials_in_hbm()) c->lds_blob_bytes = c->off[1];  // entries only (the blob starts with them)
         c->lds_scene = !strict && (size_t)c->lds_blob_bytes + acc <= lds_limit && options->lds_scene != 0;
         c->dyn_lds = (c->lds_scene ? (size_t)c->lds_blob_bytes : 0) + acc;
         const int occ = c->build->occupancy(c->variant, c->lds_scene, c->dyn_lds);

@@ -94,6 +94,12 @@ static_assert(!kFast || kCull32, "the fast build has f32 entries");
 static_assert(!kStrict || !kCull32, "the strict build has f64 entries");
 constexpr bool kPayloadAll = kCull32 && !kFast;    // product f64 build: every primitive's parameters are f64 payload slots
 constexpr bool kRigorousCull = kCull32 && !kFast;
+#ifndef MLRT_LEAN_MATERIALS_HBM
+#define MLRT_LEAN_MATERIALS_HBM 0
+#endif
+// The sphere-only variant reads its materials (one per sphere: a fifth of `random`'s f64 blob) from HBM / L2, once per shading, and
+// stages only the entries in LDS: the blob then leaves room for two workgroups per CU (KParams::lds_blob_bytes stops at the materials).
+constexpr bool kLeanMaterialsInHbm = MLRT_LEAN_MATERIALS_HBM != 0;
 constexpr bool kPerlinInHbm = !kFast;              // f64 builds: the Perlin tables stay in HBM (they end the blob; KParams::lds_blob_bytes stops before them)  // ... and its f32 culling test may never reject what an f64 primitive test accepts
 // Outward slack of the product f64 build's culling tests: reciprocal + fma instead of the reference's division moves a
 // slab distance by a few 1e-16 relative; 1e-12 is far outside that and far inside anything a box can wrongly admit.
@@ -1377,7 +1383,7 @@ void mlrt_render_kernel(const KParams<real> P) {
     __syncthreads();
     Scene S;
     S.nodes = reinterpret_cast<const DNode<creal>*>(base + P.off_nodes);
-    S.materials = reinterpret_cast<const DMaterial<real>*>(base + P.off_materials);
+    S.materials = reinterpret_cast<const DMaterial<real>*>(((FEAT == 0 && kLeanMaterialsInHbm) ? P.blob : base) + P.off_materials);
     S.textures = reinterpret_cast<const DTexture<real>*>(base + P.off_textures);
     // Perlin tables (textures.rs:51-74; 18 KB in f32, 30 KB in f64; read by marble hits only, 0.07 per sample of final_scene): in
     // LDS with the rest of the scene in the fast build, whose wave-level turbulence gathers from them in every other shading
@@ -1988,6 +1994,7 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
     return (int)hipGetLastError();
 }
 extern "C" int MLRT_CAT(mlrt_perlin_in_hbm_, MLRT_SUFFIX)(void) { return MLRT_NS::kPerlinInHbm ? 1 : 0; }
+extern "C" int MLRT_CAT(mlrt_lean_materials_in_hbm_, MLRT_SUFFIX)(void) { return MLRT_NS::kLeanMaterialsInHbm ? 1 : 0; }
 extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
 #ifdef MLRT_DEBUG_BUILD
     return 1;

@@ -12,7 +12,7 @@ if which == "f32":
     kflags = ["-DMLRT_REAL=float", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + os.environ.get("MLRT_BLOCK", "1024"), "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4")] + os.environ.get("MLRT_KERNEL_FLAGS", "").split()
 elif which in ("f64", "f64c"):
     kflags = ["-DMLRT_REAL=double", "-DMLRT_CULL=" + ("float" if which == "f64" else "double"), "-DMLRT_SUFFIX=" + which, "-DMLRT_BLOCK=" + os.environ.get("MLRT_BLOCK64", "512"), "-DMLRT_LEAN_BLOCK=" + os.environ.get("MLRT_LEAN_BLOCK64", "1024"),
-              "-DMLRT_LEAN_WAVES_PER_EU=" + os.environ.get("MLRT_LEAN_WAVES64", "4"), "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES64", "2")] + os.environ.get("MLRT_KERNEL_FLAGS64", "").split()
+              "-DMLRT_LEAN_WAVES_PER_EU=" + os.environ.get("MLRT_LEAN_WAVES64", "4"), "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES64", "2")] + (["-DMLRT_LEAN_MATERIALS_HBM=1"] if which == "f64" else []) + os.environ.get("MLRT_KERNEL_FLAGS64", "").split()
 else:
     kflags = ["-DMLRT_REAL=double", "-DMLRT_CULL=double", "-DMLRT_STRICT=1", "-DMLRT_SUFFIX=f64s", "-DMLRT_BLOCK=256", "-DMLRT_LEAN_BLOCK=256", "-DMLRT_LEAN_WAVES_PER_EU=1", "-DMLRT_FULL_WAVES_PER_EU=1"]
 flags = ["-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "--offload-arch=gfx950"] + kflags + ["-ffp-contract=off",
