@@ -201,10 +201,12 @@ typedef struct mlrt_options {
     int32_t debug_pixel, debug_sample; /* debug library only: print the path of one (pixel, sample); -1 = off */
     int32_t stall_cap;     /* 0: default.  Kernel-loop iterations a wave may spend without finishing a path before the render
                             * kernel's watchdog makes it give up (mlrt_context_check) */
+    int32_t pair_walk;     /* 1 (default): sphere-only scenes are walked through a binary BVH whose nodes hold both children's boxes, nearer
+                            * child first, with a per-lane stack in LDS (FP32 and FP64 modes); 0: the threaded list for them too */
 } mlrt_options;
 void mlrt_options_default(mlrt_options* out);
 /* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,
- * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_CULL_F64, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL, MLRT_STALL_CAP):
+ * MLRT_NO_LDS, MLRT_FORCE_FULL, MLRT_CULL_F64, MLRT_NO_PAIR_WALK, MLRT_TILE_SAMPLES, MLRT_TILE_QUEUES, MLRT_TILE_TAIL, MLRT_STATS, MLRT_DEBUG_PIXEL, MLRT_STALL_CAP):
  * the only place the library reads its environment. */
 void mlrt_options_from_env(mlrt_options* out);
 
@@ -256,6 +258,9 @@ double mlrt_context_last_kernel_ms(mlrt_context* ctx);
 /* Introspection for tests and DESIGN.md: bytes of the packed device scene, whether it is staged in LDS,
  * threads per workgroup, workgroups launched. out[4]. */
 int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]);
+/* Which render-kernel variant the context's scene runs on: 0 = FULL (every feature), 1 = sphere-only scene over the threaded entry
+ * list, 2 = sphere-only scene over the pair structure (mlrt_options.pair_walk).  Negative: NULL context. */
+int32_t mlrt_context_kernel_variant(mlrt_context* ctx);
 
 /* ---- several GPUs of one node, one process --------------------------------------------------------
  * The rows of the frame are dealt to the devices round-robin (the analogue of the reference's one-task-per-row

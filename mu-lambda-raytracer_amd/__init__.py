@@ -107,7 +107,7 @@ class Options(C.Structure):
     """mlrt_options (include/mlrt.h): tuning / diagnostic switches, none of which may change an f64 image."""
     _fields_ = [("sah", C.c_int32), ("leaf_wrap", C.c_int32), ("primary_lists", C.c_int32), ("lds_scene", C.c_int32), ("force_full", C.c_int32), ("cull_f64", C.c_int32),
                 ("tile_samples", C.c_int32), ("tile_queues", C.c_int32), ("n_tail", C.c_int32), ("tail", C.c_int32 * 8), ("stats", C.c_int32),
-                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32)]
+                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32), ("pair_walk", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
@@ -115,7 +115,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
 # every symbol declared in include/mlrt.h and include/mlrt_host.h
 EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_options_default", "mlrt_options_from_env", "mlrt_context_create",
                   "mlrt_context_create_opts", "mlrt_context_destroy", "mlrt_context_render",
-                  "mlrt_context_render_device", "mlrt_context_check", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_render", "mlrt_rows_for_device", "mlrt_multi_create",
+                  "mlrt_context_render_device", "mlrt_context_check", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_context_kernel_variant", "mlrt_render", "mlrt_rows_for_device", "mlrt_multi_create",
                   "mlrt_multi_destroy", "mlrt_multi_render", "mlrt_multi_info", "mlrt_render_multi"]
 EXPORTS_MLRT_HOST_H = ["mlrt_world_count", "mlrt_world_name", "mlrt_world_build", "mlrt_world_free", "mlrt_world_scene", "mlrt_world_camera",
                        "mlrt_world_background", "mlrt_world_stream_probes", "mlrt_camera_new", "mlrt_image_height", "mlrt_write_p3",
@@ -159,6 +159,7 @@ def lib():
         L.mlrt_context_last_kernel_ms.restype = C.c_double
         L.mlrt_context_last_kernel_ms.argtypes = [C.c_void_p]
         L.mlrt_context_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.mlrt_context_kernel_variant.argtypes = [C.c_void_p]
         L.mlrt_render.argtypes = [C.POINTER(Scene), C.POINTER(CameraStruct), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mlrt_rows_for_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.mlrt_multi_create.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(Options), C.c_int32, C.POINTER(C.c_void_p)]
@@ -332,7 +333,8 @@ class Renderer:
     def info(self):
         out = (C.c_int64 * 4)()
         _check(lib().mlrt_context_info(self.ctx, out))
-        return {"blob_bytes": int(out[0]), "lds_scene": bool(out[1]), "block_threads": int(out[2]), "grid": int(out[3])}
+        return {"blob_bytes": int(out[0]), "lds_scene": bool(out[1]), "block_threads": int(out[2]), "grid": int(out[3]),
+                "kernel_variant": {0: "full", 1: "lean-threaded", 2: "lean-pair"}.get(int(lib().mlrt_context_kernel_variant(self.ctx)), "?")}
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -52,7 +52,9 @@ UNITS = [
     # Both kernel builds pin FMA contraction OFF: every f32/f64 operation is the IEEE operation the source spells out
     # (the f64 geometry code fuses explicitly, see dfma), so the image does not depend on the compiler's inlining or on
     # which kernel variant runs.  Measured cost against -ffp-contract=fast: 1.5 % (C2) to 3.5 % (final_scene).
-    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
+    # (MLRT_LEAN_MATERIALS_HBM: with the sphere-only variant's materials read from L2, two 768-thread workgroups - scene copy, accumulators and
+    # the pair walk's stacks each - fit the 160 KB of a CU: 6 waves per SIMD; with the materials staged too only one fits: C2 49.8 instead of 37.8 ms)
+    ("kernel_f32.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=float", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f32", "-DMLRT_BLOCK=" + BLOCK, "-DMLRT_FULL_WAVES_PER_EU=" + os.environ.get("MLRT_FULL_WAVES", "4"), "-DMLRT_LEAN_MATERIALS_HBM=1", "-ffp-contract=" + os.environ.get("MLRT_FP_CONTRACT", "off")] + EXTRA_KERNEL_FLAGS + DEBUG_FLAGS + DEBUG_FLAGS_F32),
     # reference-precision build (product mode): every rounding of a sample's arithmetic where the reference has it; f32
     # culling entries with the primitives' f64 parameters in payload slots; big persistent workgroups, LDS-resident scene
     ("kernel_f64.o", KERNEL, ["--offload-arch=" + ARCH, "-DMLRT_REAL=double", "-DMLRT_CULL=float", "-DMLRT_SUFFIX=f64"] + F64_SHAPE + ["-ffp-contract=off"] + EXTRA_KERNEL_FLAGS64 + DEBUG_FLAGS),

@@ -17,7 +17,7 @@
 #include "mlrt_device.hpp"
 
 // One set of entry points per kernel build (mlrt_kernel.hip compiled with MLRT_SUFFIX = f32 | f64 | f64s).
-// variant: 0 = FULL (every feature), 1 = LEAN (see mlrt_kernel.hip)
+// variant: 0 = FULL (every feature), 1 = LEAN over the threaded list, 2 = LEAN over the pair structure (see mlrt_kernel.hip)
 #define MLRT_DECLARE_BUILD(sfx)                                                                                                    \
     int mlrt_launch_##sfx(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);                \
     int mlrt_instrumented_##sfx(void);                                                                                             \
@@ -27,7 +27,8 @@
     int mlrt_lds_frame_bytes_##sfx(void);                                                                                          \
     int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);                                                          \
     int mlrt_perlin_in_hbm_##sfx(void);                                                                                           \
-    int mlrt_lean_materials_in_hbm_##sfx(void);
+    int mlrt_lean_materials_in_hbm_##sfx(void);                                                                                    \
+    int mlrt_has_pair_walk_##sfx(void);
 extern "C" {
 MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
@@ -60,13 +61,14 @@ struct KernelBuild {
     int (*probe)(int, const void*, int, const void*, const void*, void*, void*, int, hipStream_t);  // debug library only, else nullptr
     int (*perlin_in_hbm)(void);
     int (*lean_materials_in_hbm)(void);
+    int (*has_pair_walk)(void);
 };
 #ifdef MLRT_DEBUG_BUILD
 #define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
 #else
 #define MLRT_PROBE_OF(sfx) nullptr
 #endif
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx}
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx, mlrt_has_pair_walk_##sfx}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -460,6 +462,26 @@ int32_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
     return off;
 }
 
+template <typename M>
+void pack_materials(const mlrt_scene& s, bool solid_only, std::vector<DMaterial<M>>& out) {
+    for (int i = 0; i < s.n_materials; i++) {
+        const mlrt_material& m = s.materials[i];
+        const bool textured = m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC;
+        const int32_t tex = textured ? m.texture : -1;  // (Metal / Dielectric never sample a texture, whatever the caller left in the field)
+        DMaterial<M> d{};
+        d.kind = m.kind | (texture_needs_uv(s, tex, 0) ? MATFLAG_NEEDS_UV : 0);
+        if (tex >= 0 && s.textures[tex].kind == MLRT_TEX_NOISE) d.kind |= MATFLAG_NOISE;
+        d.tex = tex;
+        for (int k = 0; k < 3; k++) d.albedo[k] = (M)m.albedo[k];
+        // a scene whose textures are all SolidColor (the LEAN kernel variant) carries the colour in the material and no
+        // texture table: 32 bytes per texture less in LDS and no dependent texture load in the shading code
+        if (solid_only && tex >= 0)
+            for (int k = 0; k < 3; k++) d.albedo[k] = (M)s.textures[tex].color[k];
+        d.param = (M)m.param;
+        out.push_back(d);
+    }
+}
+
 // `wraps`: bounding-box entries in front of sphere leaves (`wrap_leaves`) and in front of the top-level
 // entries whose miss a box can prove (primitives, medium boundaries, whole transform brackets); `sah`: SAH device BVHs.
 // None of it changes a closest hit or the conditions under which a medium draws (a ray that misses the boundary's box
@@ -544,22 +566,7 @@ Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool wrap_leaves, bool sah, b
         }
         MLRT_REQUIRE(P.entries.size() == after, "internal error: entry count of an object");
     }
-    for (int i = 0; i < s.n_materials; i++) {
-        const mlrt_material& m = s.materials[i];
-        const bool textured = m.kind == MLRT_MAT_LAMBERTIAN || m.kind == MLRT_MAT_DIFFUSE_LIGHT || m.kind == MLRT_MAT_ISOTROPIC;
-        const int32_t tex = textured ? m.texture : -1;  // (Metal / Dielectric never sample a texture, whatever the caller left in the field)
-        DMaterial<M> d{};
-        d.kind = m.kind | (texture_needs_uv(s, tex, 0) ? MATFLAG_NEEDS_UV : 0);
-        if (tex >= 0 && s.textures[tex].kind == MLRT_TEX_NOISE) d.kind |= MATFLAG_NOISE;
-        d.tex = tex;
-        for (int k = 0; k < 3; k++) d.albedo[k] = (M)m.albedo[k];
-        // a scene whose textures are all SolidColor (the LEAN kernel variant) carries the colour in the material and no
-        // texture table: 32 bytes per texture less in LDS and no dependent texture load in the shading code
-        if (solid_only && tex >= 0)
-            for (int k = 0; k < 3; k++) d.albedo[k] = (M)s.textures[tex].color[k];
-        d.param = (M)m.param;
-        P.materials.push_back(d);
-    }
+    pack_materials<M>(s, solid_only, P.materials);
     for (int i = 0; i < s.n_textures && !solid_only; i++) {
         const mlrt_texture& t = s.textures[i];
         DTexture<M> d{};
@@ -595,6 +602,126 @@ Packed<R, M> pack(const mlrt_scene& s, bool wraps, bool wrap_leaves, bool sah, b
     return P;
 }
 
+
+// ---- the pair walk's structure (mlrt_device.hpp DPair): sphere-only scenes --------------------------------------------------
+// Every sphere of the world - top-level primitives and the leaves of every BHV, numbered in the order the reference visits them
+// (hittable.rs:57-66 list order, bhv.rs:152-163 left before right) - under ONE surface-area-heuristic binary tree whose nodes hold
+// both children's boxes.  Legal because a closest hit over spheres does not depend on how they are grouped (the same argument as
+// for the SAH threaded list above), with the tie rule of the sphere test (mlrt_kernel.hip) keeping equal distances the
+// reference's way.  M = the primitives' and materials' type (float: fast build, double: product f64 build).
+template <typename M>
+struct PackedPairs {
+    std::vector<DPair> pairs;
+    std::vector<M> prims;  // [n_prims][4]: centre, radius
+    std::vector<uint16_t> prim_mat;
+    std::vector<DMaterial<M>> materials;
+    std::vector<unsigned char> blob;
+    int32_t off_pairs = 0, off_prims = 0, off_prim_mat = 0, off_materials = 0;
+    int32_t n_prims = 0, stack_levels = 0;
+};
+struct PairItem {
+    int32_t prim;
+    Bounds b;
+    double c[3];
+};
+constexpr int kPairLevelCap = 24;  // inner nodes on any root-to-leaf path (= rows of a lane's LDS stack): below it the builder splits by count
+inline int ceil_log2(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return l; }
+// Builds the subtree over items[begin, end) (>= 1 item); returns its reference and bounds.  `level` = inner nodes above it.
+template <typename M>
+int32_t build_pairs(std::vector<PairItem>& items, size_t begin, size_t end, int level, Round round, PackedPairs<M>& out, Bounds& bounds) {
+    const size_t n = end - begin;
+    if (n == 1) { bounds = items[begin].b; return kPairLeaf + items[begin].prim; }
+    size_t split = begin + n / 2;
+    int axis = 0;
+    if (kPairLevelCap - level <= ceil_log2(n)) {
+        // out of levels for anything but a balanced tree: median split along the widest extent of the centroids
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = begin; i < end; i++) for (int a = 0; a < 3; a++) { lo[a] = std::fmin(lo[a], items[i].c[a]); hi[a] = std::fmax(hi[a], items[i].c[a]); }
+        for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+    } else {
+        double best_cost = INFINITY;
+        std::vector<double> right_area(n);
+        for (int a = 0; a < 3; a++) {
+            std::stable_sort(items.begin() + begin, items.begin() + end, [a](const PairItem& x, const PairItem& y) { return x.c[a] < y.c[a]; });
+            Bounds acc = empty_bounds();
+            for (size_t i = n; i-- > 1;) { acc.grow(items[begin + i].b); right_area[i] = acc.half_area(); }
+            acc = empty_bounds();
+            for (size_t i = 1; i < n; i++) {
+                acc.grow(items[begin + i - 1].b);
+                const double cost = acc.half_area() * (double)i + right_area[i] * (double)(n - i);
+                if (cost < best_cost) { best_cost = cost; axis = a; split = begin + i; }
+            }
+        }
+    }
+    std::stable_sort(items.begin() + begin, items.begin() + end, [axis](const PairItem& x, const PairItem& y) { return x.c[axis] < y.c[axis]; });
+    const int32_t me = (int32_t)out.pairs.size();
+    out.pairs.push_back(DPair{});
+    out.stack_levels = std::max(out.stack_levels, level + 1);
+    Bounds ba, bb;
+    const int32_t ra = build_pairs<M>(items, begin, split, level + 1, round, out, ba);
+    const int32_t rb = build_pairs<M>(items, split, end, level + 1, round, out, bb);
+    DPair& p = out.pairs[(size_t)me];
+    for (int k = 0; k < 3; k++) {
+        p.a[k] = round_down<float>(ba.lo[k], round); p.a[3 + k] = round_up<float>(ba.hi[k], round);
+        p.b[k] = round_down<float>(bb.lo[k], round); p.b[3 + k] = round_up<float>(bb.hi[k], round);
+    }
+    p.ref_a = ra; p.ref_b = rb;
+    bounds = ba;
+    bounds.grow(bb);
+    return me;
+}
+// The spheres of a sphere-only world in the reference's visiting order (as indices into s.spheres).
+void spheres_in_reference_order(const mlrt_scene& s, std::vector<int32_t>& order) {
+    for (int i = 0; i < s.n_objects; i++) {
+        const mlrt_object& src = s.objects[i];
+        if (src.kind == MLRT_OBJ_PRIM) { order.push_back(src.prim.index); continue; }
+        const int32_t root = s.bvhs[src.bvh].root;  // (MLRT_OBJ_BVH: a sphere-only world has no media)
+        if (root == MLRT_BVH_EMPTY) continue;
+        std::vector<int32_t> refs;
+        int budget = 2 * s.n_bvh_nodes + s.n_prim_refs + 2;
+        collect_leaves(s, root, refs, budget);
+        for (int32_t r : refs) order.push_back(s.prim_refs[r].index);
+    }
+}
+// false: the world is outside what the pair walk covers (no sphere at all, or too many for 16-bit references)
+template <typename M>
+bool pack_pairs(const mlrt_scene& s, Round round, PackedPairs<M>& P) {
+    std::vector<int32_t> order;
+    spheres_in_reference_order(s, order);
+    if (order.empty() || order.size() > (size_t)kPairMaxPrims) return false;
+    P.n_prims = (int32_t)order.size();
+    std::vector<PairItem> items(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        const mlrt_sphere& sp = s.spheres[order[k]];
+        P.prims.push_back((M)sp.center[0]); P.prims.push_back((M)sp.center[1]); P.prims.push_back((M)sp.center[2]); P.prims.push_back((M)sp.radius);
+        P.prim_mat.push_back((uint16_t)sp.material);
+        items[k].prim = (int32_t)k;
+        const mlrt_prim_ref ref{MLRT_PRIM_SPHERE, order[k]};
+        prim_bounds(s, ref, items[k].b);
+        for (int a = 0; a < 3; a++) items[k].c[a] = 0.5 * (items[k].b.lo[a] + items[k].b.hi[a]);
+    }
+    if (s.n_materials > 65535) return false;
+    Bounds all;
+    const int32_t root = build_pairs<M>(items, 0, items.size(), 0, round, P, all);
+    if (root < 0) {
+        // a single sphere: one node whose two children are that leaf (the second test finds the same distance from the same
+        // primitive and changes nothing)
+        DPair p{};
+        for (int k = 0; k < 3; k++) { p.a[k] = p.b[k] = round_down<float>(all.lo[k], round); p.a[3 + k] = p.b[3 + k] = round_up<float>(all.hi[k], round); }
+        p.ref_a = p.ref_b = root;
+        P.pairs.push_back(p);
+        P.stack_levels = 1;
+    }
+    if (P.pairs.size() > (size_t)kPairMaxNodes) return false;
+    pack_materials<M>(s, true, P.materials);
+    P.off_pairs = append(P.blob, P.pairs);
+    P.off_prims = append(P.blob, P.prims);
+    P.off_prim_mat = append(P.blob, P.prim_mat);
+    while (P.blob.size() % 16) P.blob.push_back(0);
+    P.off_materials = append(P.blob, P.materials);
+    while (P.blob.size() % 16) P.blob.push_back(0);
+    return true;
+}
 }  // namespace
 }  // namespace mlrt
 
@@ -609,6 +736,8 @@ struct mlrt_context {
     int32_t blob_bytes = 0, lds_blob_bytes = 0;
     int32_t off[6] = {0, 0, 0, 0, 0, 0};
     int32_t n_nodes = 0, n_sphere_index = 0;
+    bool pair_walk = false;  // the blob is the pair structure (mlrt_device.hpp DPair), variant == 2
+    int32_t off_prims = 0, off_prim_mat = 0, n_prims = 0, stack_levels = 0;
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
     unsigned int* d_tile_counter = nullptr;
@@ -618,7 +747,7 @@ struct mlrt_context {
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_acc = nullptr;  // frame accumulation buffer, grown on demand
     size_t acc_elems = 0;
-    int32_t variant = 0;  // kernel variant (0 FULL, 1 LEAN)
+    int32_t variant = 0;  // kernel variant (0 FULL, 1 LEAN, 2 LEAN over the pair structure)
     uint32_t features = 0;
     bool lds_scene = false;
     size_t dyn_lds = 0;
@@ -714,8 +843,8 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, const m
 // stays small against the frame, and max_depth small enough for the list cursor the kernel keeps in the upper bits of a
 // lane's depth word (max_depth is any i32 in the reference: above 65535 the lanes simply walk the BVH).
 bool primary_lists_wanted(const mlrt_context* c, const mlrt_params* p) {
-    return c->variant == 1 && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && c->n_nodes <= 4096 && p->image_height < 65536 &&
-           p->max_depth <= 0xFFFF;
+    return c->variant >= 1 && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && (c->pair_walk ? c->n_prims : c->n_nodes) <= 4096 &&
+           p->image_height < 65536 && p->max_depth <= 0xFFFF;
 }
 
 template <typename R>
@@ -726,6 +855,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
     K.off_sphere_index = c->off[5]; K.n_sphere_index = c->n_sphere_index;
     K.n_nodes = c->n_nodes;
+    K.pair_walk = c->pair_walk ? 1 : 0; K.off_prims = c->off_prims; K.off_prim_mat = c->off_prim_mat; K.n_prims = c->n_prims; K.stack_levels = c->stack_levels;
     K.images = c->d_images;
     for (int k = 0; k < 3; k++) {
         K.cam_origin[k] = cam->origin[k]; K.cam_llc[k] = cam->lower_left_corner[k];
@@ -741,7 +871,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
     TilePlan T;
-    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant == 1, c->opt, T);
+    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant >= 1, c->opt, T);
     MLRT_REQUIRE(T.n_tiles < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
     K.pix_per_tile = T.pix_per_tile; K.tiles_per_row = T.tiles_per_row; K.n_groups = T.n_groups; K.n_big = T.n_big; K.big = T.big; K.n_tail = T.n_tail;
     for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = T.tail_s0[k];
@@ -862,6 +992,33 @@ void mlrt_debug_tile_plan(int32_t width, int32_t n_rows, int32_t spp, int32_t wa
     for (int i = 0; i <= mlrt::kMaxTailPasses; i++) out[k++] = T.tail_s0[i];
     out[k++] = T.n_tiles; out[k++] = T.n_groups_magic; out[k++] = T.n_groups_shift; out[k++] = T.tiles_per_row_magic; out[k++] = T.tiles_per_row_shift;
 }
+// Test hook (not part of include/mlrt.h): the pair structure the packer builds for a sphere-only scene (mlrt_device.hpp DPair), as
+// the blob a context would upload.  precision: MLRT_PRECISION_FP32 (f32 primitives) or MLRT_PRECISION_FP64 (f64 primitives, rigorous
+// outward rounding).  info = blob bytes, off_pairs, n_pairs, off_prims, off_prim_mat, n_prims, stack_levels, off_materials.
+// Returns MLRT_ERR_UNSUPPORTED when the scene is outside what the pair walk covers.  Free *blob_out with mlrt_free.  No device call.
+int32_t mlrt_debug_pack_pairs(const mlrt_scene* scene, int32_t precision, unsigned char** blob_out, int64_t info[8]) {
+    return guarded([&] {
+        MLRT_REQUIRE(scene && blob_out && info, "NULL argument");
+        validate(*scene);
+        if (scene_features(*scene) != 0) throw Fail{MLRT_ERR_UNSUPPORTED, "the pair walk serves sphere-only scenes with solid-colour materials"};
+        auto give = [&](auto& Q) {
+            *blob_out = static_cast<unsigned char*>(std::malloc(Q.blob.size()));
+            MLRT_REQUIRE(*blob_out, "out of memory");
+            std::memcpy(*blob_out, Q.blob.data(), Q.blob.size());
+            const int64_t v[8] = {(int64_t)Q.blob.size(), Q.off_pairs, (int64_t)Q.pairs.size(), Q.off_prims, Q.off_prim_mat, Q.n_prims, Q.stack_levels, Q.off_materials};
+            std::memcpy(info, v, sizeof v);
+        };
+        if (precision == MLRT_PRECISION_FP32) {
+            PackedPairs<float> Q;
+            if (!pack_pairs<float>(*scene, Round::OUTWARD, Q)) throw Fail{MLRT_ERR_UNSUPPORTED, "scene outside the pair walk's limits"};
+            give(Q);
+        } else {
+            PackedPairs<double> Q;
+            if (!pack_pairs<double>(*scene, Round::RIGOROUS, Q)) throw Fail{MLRT_ERR_UNSUPPORTED, "scene outside the pair walk's limits"};
+            give(Q);
+        }
+    });
+}
 void mlrt_version(int32_t* major, int32_t* minor) {
     if (major) *major = MLRT_VERSION_MAJOR;
     if (minor) *minor = MLRT_VERSION_MINOR;
@@ -876,7 +1033,7 @@ int32_t mlrt_device_count(void) {
 void mlrt_options_default(mlrt_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);
-    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0;
+    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0; o->pair_walk = 1;
     o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
     o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0; o->stall_cap = 0;
 }
@@ -890,6 +1047,7 @@ void mlrt_options_from_env(mlrt_options* o) {
     if (std::getenv("MLRT_NO_LDS")) o->lds_scene = 0;
     if (std::getenv("MLRT_FORCE_FULL")) o->force_full = 1;
     if (std::getenv("MLRT_CULL_F64")) o->cull_f64 = 1;
+    if (std::getenv("MLRT_NO_PAIR_WALK")) o->pair_walk = 0;
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) o->tile_samples = std::atoi(ts);
     if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) o->tile_queues = std::atoi(nq);
     if (const char* spec = std::getenv("MLRT_TILE_TAIL")) {
@@ -953,7 +1111,33 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         const size_t lds_limit = 160 * 1024;
         const size_t lds_other = (size_t)(c->block_threads / 64) * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
         auto fits_lds = [&](const auto& P) { return (size_t)(c->build->perlin_in_hbm() ? P.off_perlin_vec : (int32_t)P.blob.size()) + lds_other <= lds_limit; };
-        if (precision == MLRT_PRECISION_FP32) {
+        // Sphere-only scenes: the pair structure (mlrt_device.hpp DPair) when the build has the walk, the spheres fit its 16-bit
+        // references and the lanes' stacks fit the LDS; otherwise the threaded list below.
+        size_t pair_stack_bytes = 0;
+        auto take_pairs = [&](auto& Q) {
+            const size_t stack = (size_t)(Q.stack_levels + 1) * (size_t)c->block_threads * sizeof(int16_t);  // (mlrt_kernel.hip: one guard row below the stack)
+            if (stack + lds_other + 1024 > lds_limit) return;  // (even with the scene in HBM the stacks must fit)
+            blob.swap(Q.blob);
+            const int32_t o[6] = {Q.off_pairs, Q.off_materials, (int32_t)blob.size(), (int32_t)blob.size(), (int32_t)blob.size(), (int32_t)blob.size()};
+            std::memcpy(c->off, o, sizeof o);
+            c->n_nodes = (int32_t)Q.pairs.size();
+            c->n_sphere_index = 0;
+            c->pair_walk = true; c->variant = 2;
+            c->off_prims = Q.off_prims; c->off_prim_mat = Q.off_prim_mat; c->n_prims = Q.n_prims; c->stack_levels = Q.stack_levels;
+            pair_stack_bytes = stack;
+        };
+        if (c->variant == 1 && options->pair_walk != 0 && !strict && !(precision == MLRT_PRECISION_FP64 && options->cull_f64) && c->build->has_pair_walk()) {
+            if (precision == MLRT_PRECISION_FP32) {
+                PackedPairs<float> Q;
+                if (pack_pairs<float>(*scene, Round::OUTWARD, Q)) take_pairs(Q);
+            } else {
+                PackedPairs<double> Q;
+                if (pack_pairs<double>(*scene, Round::RIGOROUS, Q)) take_pairs(Q);
+            }
+        }
+        if (c->pair_walk) {
+            // (packed above)
+        } else if (precision == MLRT_PRECISION_FP32) {
             auto P = pack<float, float>(*scene, wraps, true, sah, solid_only, false, Round::OUTWARD);
             take(P);
         } else if (precision == MLRT_PRECISION_FP64 && !options->cull_f64) {
@@ -1008,10 +1192,10 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         // LDS plan: the blob is staged in LDS when it fits next to the per-wave accumulators and the frame parameters
         // (the strict build is a test instrument: small workgroups reading the blob through L2)
         const int waves = c->block_threads / 64;
-        const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
+        const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes() + pair_stack_bytes;
         // (f64 builds read the Perlin tables - the blob's tail - from HBM: they alone would keep final_scene's blob out of LDS)
         c->lds_blob_bytes = c->build->perlin_in_hbm() ? c->off[3] : (int32_t)blob.size();
-        if (c->variant == 1 && c->build->lean_materials_in_hbm()) c->lds_blob_bytes = c->off[1];  // entries only (the blob starts with them)
+        if (c->variant >= 1 && c->build->lean_materials_in_hbm()) c->lds_blob_bytes = c->off[1];  // entries only (the blob starts with them)
         c->lds_scene = !strict && (size_t)c->lds_blob_bytes + acc <= lds_limit && options->lds_scene != 0;
         c->dyn_lds = (c->lds_scene ? (size_t)c->lds_blob_bytes : 0) + acc;
         const int occ = c->build->occupancy(c->variant, c->lds_scene, c->dyn_lds);
@@ -1111,6 +1295,8 @@ int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]) {
     out[3] = ctx->last_grid > 0 ? ctx->last_grid : (int64_t)ctx->n_cus * ctx->blocks_per_cu;
     return MLRT_OK;
 }
+
+int32_t mlrt_context_kernel_variant(mlrt_context* ctx) { return ctx ? ctx->variant : -1; }
 
 // Debug only (MLRT_STATS=1; not part of the ABI headers): copies and clears the in-kernel counters.
 int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[16]) {

@@ -55,6 +55,27 @@ struct alignas(sizeof(R) == 4 ? 16 : 64) DNode {
 static_assert(sizeof(DNode<float>) == 32, "f32 entry must be 32 bytes (two ds_read_b128)");
 static_assert(sizeof(DNode<double>) == 64, "f64 entry is one 64-byte line");
 
+// ---- the pair walk (sphere-only scenes, builds with f32 culling) ---------------------------------------------------
+// The second device structure: a binary BVH whose node holds the boxes of BOTH its children (bhv.rs:147-165: the
+// reference's Node::hit tests its own box, then recurses left, then right with tmax shrunk; here a visit of a node
+// decides both children at once, enters the nearer one and pushes the other on a short per-lane stack in LDS).  One
+// visit = one LDS round trip (four ds_read_b128) where the threaded list pays one round trip per box.  A child
+// reference is a pair index (>= 0), a leaf (kPairLeaf + primitive index, negative) or - only ever at the bottom of a
+// lane's stack - kPairEnd.  References are 16-bit quantities (the stack stores them as such), sign-extended.
+// Leaves are primitive indices into `prims` (4 reals: centre, radius; f64 in the product build) in the REFERENCE's
+// visiting order (top-level list order, then each BVH's leaves left to right): the sphere test accepts a hit at the
+// same distance as the closest so far only from a primitive of higher index - what the reference's `t <= closest_so_far`
+// (shapes.rs:66-73 with hittable.rs:58-66) does when it visits them in that order - so the result does not depend on the
+// order the device visits them in.
+struct alignas(16) DPair {
+    float a[6];  // child A: min xyz, max xyz (f32, moved outward like the threaded entries)
+    float b[6];  // child B
+    int32_t ref_a, ref_b;
+    int32_t pad[2];
+};
+static_assert(sizeof(DPair) == 64, "a pair node is four ds_read_b128");
+enum : int32_t { kPairEnd = -1, kPairLeaf = -32768, kPairMaxPrims = 32767, kPairMaxNodes = 32768 };
+
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
 #define MLRT_HD __host__ __device__
 #else
@@ -109,6 +130,11 @@ struct KParams {
     int32_t off_nodes, off_materials, off_textures, off_perlin_vec, off_perlin_perm;
     int32_t off_sphere_index, n_sphere_index;  // u16 entry indices of the sphere entries, in entry order (the candidate pre-pass scans these)
     int32_t n_nodes;
+    // pair walk (DPair): off_nodes is then the offset of the pair nodes, n_nodes their number
+    int32_t pair_walk;                 // 1: the blob holds [pairs | prims | prim_mat | materials], the kernel is the PAIR variant
+    int32_t off_prims, off_prim_mat;   // prims: [n_prims][4] reals (centre, radius); prim_mat: [n_prims] u16 material indices
+    int32_t n_prims;
+    int32_t stack_levels;              // rows of the per-lane LDS stack (the longest chain of inner nodes from the root)
     const DImage* images;
     // Camera (camera.rs:3-12): f64 in both builds, primary rays are generated exactly as the reference does
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];

@@ -450,6 +450,10 @@ struct Scene {
     const real* perlin_vec;         // [tables][1024][3]
     const uint16_t* perlin_perm;    // [tables][3][1024]
     const DImage* images;           // HBM (L2-resident)
+    // the pair walk (mlrt_device.hpp DPair; sphere-only scenes): `nodes` is then unused
+    const DPair* pairs;
+    const real* prims;              // [n_prims][4]: centre, radius
+    const uint16_t* prim_mat;       // [n_prims]
 };
 // The f64 parameters of the primitive whose entry is `idx` (mlrt_device.hpp: payload slots behind an f32 entry, inline in an
 // f64 entry; the fast build computes boxes, rects, media and transforms from the entry's inline f32 values).
@@ -461,6 +465,12 @@ DEV SphereP sphere_params(const Scene& S, int idx, const DNode<creal>& n) {
     SphereP s;
     if (kPayloadAll) { const double* p = payload(S, idx); s.cx = p[0]; s.cy = p[1]; s.cz = p[2]; s.r = p[3]; }
     else { s.cx = (double)n.v[0]; s.cy = (double)n.v[1]; s.cz = (double)n.v[2]; s.r = (double)n.v[3]; }
+    return s;
+}
+DEV SphereP pair_sphere(const Scene& S, int prim) {  // pair walk: primitive `prim` of S.prims (one 16- or 32-byte read)
+    SphereP s;
+    const real* q = S.prims + 4 * prim;
+    s.cx = (double)q[0]; s.cy = (double)q[1]; s.cz = (double)q[2]; s.r = (double)q[3];
     return s;
 }
 template <int N>
@@ -629,6 +639,18 @@ DEV bool slab_hit_fast(const DNode<creal>& n, const SlabRay& r, float closest_sl
     tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
     // (closest_slack and tnear are positive and not NaN - tnear >= 0.001 by the fmaxf above - so the second comparison is done
     // on the bit patterns: written on floats the compiler folds the two back into one min, canonicalisation included)
+    return !(tfar * kSlack32 <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
+}
+// One child box of a pair node (f32 culling builds only): the decision of slab_hit_fast, and the entry distance the
+// near-first order is taken from.
+DEV bool slab_child(const float (&v)[6], const SlabRay& r, float closest_slack, float& tnear_out) {
+    float t0 = __builtin_fmaf(v[0], (float)r.ix, (float)r.ofx), t1 = __builtin_fmaf(v[3], (float)r.ix, (float)(kRigorousCull ? r.of2x : r.ofx));
+    float tnear = fmaxf(fminf(t0, t1), 0.001f), tfar = fmaxf(t0, t1);
+    t0 = __builtin_fmaf(v[1], (float)r.iy, (float)r.ofy); t1 = __builtin_fmaf(v[4], (float)r.iy, (float)(kRigorousCull ? r.of2y : r.ofy));
+    tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
+    t0 = __builtin_fmaf(v[2], (float)r.iz, (float)r.ofz); t1 = __builtin_fmaf(v[5], (float)r.iz, (float)(kRigorousCull ? r.of2z : r.ofz));
+    tnear = fmaxf(fminf(t0, t1), tnear); tfar = fminf(fmaxf(t0, t1), tfar);
+    tnear_out = tnear;
     return !(tfar * kSlack32 <= tnear) && !(__builtin_bit_cast(int, closest_slack) <= __builtin_bit_cast(int, tnear));
 }
 // closest-so-far as the slab tests of the current build want it
@@ -969,8 +991,25 @@ struct HitAttr {
     bool front_face;
     DMaterial<real> m;
 };
-template <uint32_t FEAT>
+template <uint32_t FEAT, bool PAIR = false>
 DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
+    if constexpr (PAIR) {  // pair walk: c.hit_node is a primitive index, every primitive a sphere with a solid-colour material
+        const SphereP sp = pair_sphere(S, c.hit_node);
+        const P3 po = ray_at(o, d, c.closest);
+        V3 outward;
+        if (kFast) outward = to_v3(po - mkp(sp.cx, sp.cy, sp.cz)) * fast_rcp((real)sp.r);
+        else {
+            double nx, ny, nz;
+            Divisor(sp.r).over(po.x - sp.cx, po.y - sp.cy, po.z - sp.cz, nx, ny, nz);
+            outward = mk((real)nx, (real)ny, (real)nz);
+        }
+        HitAttr h;
+        h.front_face = dot(outward, to_v3(d)) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
+        h.normal = h.front_face ? outward : -outward;
+        h.p = po; h.u = (real)0; h.v = (real)0;
+        h.m = S.materials[S.prim_mat[c.hit_node]];
+        return h;
+    }
     const DNode<creal> n = S.nodes[c.hit_node];
     const int kind = n.tag & TAG_KIND_MASK;
     P3 p;
@@ -1217,6 +1256,23 @@ DEV DNode<creal> fetch_entry(const Scene& S, int node, int n_nodes) { return S.n
 DEV void pin_entry(const DNode<creal>& n) {
     asm volatile("" : : "v"(n.v[0]), "v"(n.v[1]), "v"(n.v[2]), "v"(n.v[3]), "v"(n.v[4]), "v"(n.v[5]), "v"(n.link), "v"(n.tag));
 }
+// pair walk: the node a lane visits next (four ds_read_b128 in one round trip); a lane parked on a leaf or finished reads node 0
+DEV DPair fetch_pair(const Scene& S, int ref) { return S.pairs[ref < 0 ? 0 : ref]; }
+DEV void pin_entry(const DPair& n) {
+    asm volatile("" : : "v"(n.a[0]), "v"(n.a[1]), "v"(n.a[2]), "v"(n.a[3]), "v"(n.a[4]), "v"(n.a[5]), "v"(n.b[0]), "v"(n.b[1]), "v"(n.b[2]), "v"(n.b[3]), "v"(n.b[4]), "v"(n.b[5]),
+                 "v"(n.ref_a), "v"(n.ref_b));
+}
+template <bool PAIR> struct EntryOf { typedef DNode<creal> type; };
+template <> struct EntryOf<true> { typedef DPair type; };
+#ifndef MLRT_PAIR_SPECIAL_ROUNDS
+#define MLRT_PAIR_SPECIAL_ROUNDS 1
+#endif
+// Traversal steps between two looks at the batches (MLRT_STEPS for the threaded list).  A pair visit does the work of ~2.3 list
+// steps, so the batches want looking at twice as often (measured, C2 kernel ms f64 / f32: 4 steps 53.5 / 37.8, 2 steps 52.3 / 36.4,
+// 3 steps in between; the threaded list on the same box 55.6 / 38.5).
+#ifndef MLRT_PAIR_STEPS
+#define MLRT_PAIR_STEPS 2
+#endif
 
 // Primary rays of a pixel group (1-4 neighbouring pixels; pinhole camera, for a thin lens see below) all lie inside the
 // pyramid from the camera origin through the group's footprint on the image plane, so they can only hit the spheres
@@ -1234,6 +1290,7 @@ constexpr int kCoarseMax = 256;
 // pyramid of the whole 64-group span (64 entries per round, survivors compacted into LDS in entry order: typically 10-30),
 // then every lane tests only those against its own group's pyramid.  (A flat scan of all entries per group cost 0.5 ms per
 // C2 frame.)  A span with more than kCoarseMax survivors falls back to the flat scan.
+template <bool PAIR>
 __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<real> P, uint16_t* records) {
     __shared__ uint16_t coarse[kCoarseMax];
     const int lane = threadIdx.x;
@@ -1278,10 +1335,10 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     // (the sphere entries are listed in the blob: payload slots make the entry array unsafe to scan blindly)
     const uint16_t* sphere_index = reinterpret_cast<const uint16_t*>(P.blob + P.off_sphere_index);
     auto touches = [&](const Pyramid& py, int e) {
-        const DNode<creal> q = nodes[e];
         double cx, cy, cz, rad;
-        if (kPayloadAll) { const double* pl = reinterpret_cast<const double*>(&nodes[e + 1]); cx = pl[0]; cy = pl[1]; cz = pl[2]; rad = pl[3]; }
-        else { cx = (double)q.v[0]; cy = (double)q.v[1]; cz = (double)q.v[2]; rad = (double)q.v[3]; }
+        if (PAIR) { const real* q = reinterpret_cast<const real*>(P.blob + P.off_prims) + 4 * e; cx = (double)q[0]; cy = (double)q[1]; cz = (double)q[2]; rad = (double)q[3]; }
+        else if (kPayloadAll) { const double* pl = reinterpret_cast<const double*>(&nodes[e + 1]); cx = pl[0]; cy = pl[1]; cz = pl[2]; rad = pl[3]; }
+        else { const DNode<creal> q = nodes[e]; cx = (double)q.v[0]; cy = (double)q.v[1]; cz = (double)q.v[2]; rad = (double)q.v[3]; }
         const V3 cc = mk((real)cx, (real)cy, (real)cz) - of;
         const real radius = abs_r((real)rad);
         const real far = abs_r(cc.x) + abs_r(cc.y) + abs_r(cc.z);  // >= |cc|
@@ -1291,10 +1348,11 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     // level 1: the span's survivors, in entry order
     const Pyramid span = pyramid(gx0 * P.pix_per_tile, min(P.width, (gx0 + 64) * P.pix_per_tile));
     int n_coarse = 0;  // wave-uniform
-    for (int k0 = 0; k0 < P.n_sphere_index; k0 += 64) {
+    const int n_index = PAIR ? P.n_prims : P.n_sphere_index;  // (pair walk: the candidates are primitive indices, every primitive a sphere)
+    for (int k0 = 0; k0 < n_index; k0 += 64) {
         const int k = k0 + lane;
-        const int e = (int)sphere_index[k < P.n_sphere_index ? k : 0];
-        const bool in = k < P.n_sphere_index && touches(span, e);
+        const int e = PAIR ? (k < n_index ? k : 0) : (int)sphere_index[k < n_index ? k : 0];
+        const bool in = k < n_index && touches(span, e);
         const unsigned long long mask = __ballot(in);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
         if (in && n_coarse + rank < kCoarseMax) coarse[n_coarse + rank] = (uint16_t)e;
@@ -1302,7 +1360,7 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     }
     __syncthreads();
     const bool flat = n_coarse > kCoarseMax;
-    const int n_candidates = flat ? P.n_sphere_index : n_coarse;
+    const int n_candidates = flat ? n_index : n_coarse;
     // level 2: the lane's own pixel group
     if (gx >= P.tiles_per_row) return;
     const int x0 = gx * P.pix_per_tile;
@@ -1312,7 +1370,7 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     for (int k = 0; k < kCandRecord; k++) list[k] = 0;
     int count = 0;
     for (int k = 0; k < n_candidates; k++) {
-        const int e = flat ? (int)sphere_index[k] : (int)coarse[k];
+        const int e = flat ? (PAIR ? k : (int)sphere_index[k]) : (int)coarse[k];
         if (touches(own, e)) {
 #pragma unroll
             for (int m = 0; m < kCand; m++) if (m == count) list[1 + m] = (uint16_t)e;
@@ -1349,9 +1407,10 @@ DEV unsigned int* watchdog_record() {
 #ifndef MLRT_FULL_WAVES_PER_EU
 #define MLRT_FULL_WAVES_PER_EU 1
 #endif
-template <bool LDS_SCENE, uint32_t FEAT, int BLOCK>
+template <bool LDS_SCENE, uint32_t FEAT, int BLOCK, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0 ? MLRT_LEAN_WAVES_PER_EU : MLRT_FULL_WAVES_PER_EU)))
 void mlrt_render_kernel(const KParams<real> P) {
+    static_assert(!PAIR || (FEAT == 0 && kCull32), "the pair walk serves sphere-only scenes in the builds with f32 culling");
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the wave's LDS addresses are SGPR + immediate
@@ -1392,6 +1451,18 @@ void mlrt_render_kernel(const KParams<real> P) {
     S.perlin_vec = reinterpret_cast<const real*>((kPerlinInHbm ? P.blob : base) + P.off_perlin_vec);
     S.perlin_perm = reinterpret_cast<const uint16_t*>((kPerlinInHbm ? P.blob : base) + P.off_perlin_perm);
     S.images = P.images;
+    S.pairs = reinterpret_cast<const DPair*>(base + P.off_nodes);
+    S.prims = reinterpret_cast<const real*>(base + P.off_prims);
+    S.prim_mat = reinterpret_cast<const uint16_t*>(base + P.off_prim_mat);
+    // Pair walk: the lane's traversal stack, rows of BLOCK 16-bit references behind the frame parameters (row r of lane l at
+    // [r * BLOCK + l]; P.stack_levels rows are ever written).  The newest reference lives in `top`; rows 1 .. sp / BLOCK - 1 hold the
+    // older ones, kPairEnd first.  Row 0 is only ever read (by the pop that takes kPairEnd out of `top`: the value is never looked at).
+    // (Measured and not kept: `top` stored and the row below it re-read by every lane after every step, so that neither push nor pop
+    // waits for the LDS inside a step and the step has no branch but the outer one: 3 % slower in both builds - the visit is bound by
+    // the instructions it issues, not by the pop's round trip.  Only traversing lanes fetching their next node: +0.5 %.  Two rounds of
+    // the sphere batch for lanes whose pop is another leaf: +2 %.)
+    int16_t* const stack_lane = reinterpret_cast<int16_t*>(acc_base + (BLOCK / 64) * kAccBytesPerWave + kFrameParamBytes) + threadIdx.x;
+    int sp = BLOCK, top = kPairEnd;
 
     const int n_banks = P.n_banks, bank_vals = P.bank_values;  // wave-uniform
     int* bank_remaining = reinterpret_cast<int*>(acc_base + wave * kAccBytesPerWave);  // samples of the bank's tile not yet finished
@@ -1475,7 +1546,8 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (lane == 0) { atomicAdd(&status_[0], 1u); status_[1] = (unsigned int)blockIdx.x; status_[2] = (unsigned int)wave; }               \
         status_[4 + lane] = (unsigned int)phase | ((unsigned int)has_path << 8) | ((unsigned int)(c.node & 0xFFFF) << 16);                  \
     } while (0)
-    DNode<creal> n = fetch_entry(S, 0, n_nodes);  // always the entry at c.node (any lane, any phase)
+    typename EntryOf<PAIR>::type n;  // always the entry at c.node (any lane, any phase)
+    if constexpr (PAIR) n = fetch_pair(S, 0); else n = fetch_entry(S, 0, n_nodes);
     for (;;) {
         // (A) MLRT_STEPS traversal steps between two looks at the batches: the ballots and threshold tests of (B) and (C)
         // are a fifth of an iteration's instructions, and a lane that parks waits at most three steps longer for
@@ -1487,14 +1559,27 @@ void mlrt_render_kernel(const KParams<real> P) {
         if (MLRT_STATS_ON(P)) st_c0 = __builtin_readcyclecounter();
         creal far_bound = slab_far_bound(c.closest);  // (hits are accepted in the batches, and by box entries in the full variant's step)
 #pragma unroll
-        for (int sub = 0; sub < MLRT_STEPS; sub++) {
+        for (int sub = 0; sub < (PAIR ? MLRT_PAIR_STEPS : MLRT_STEPS); sub++) {
         pin_entry(n);
         if (MLRT_STATS_ON(P)) { st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth)); }
         // The array ends in a TAG_END sentinel, so there is no bounds test.  Two shapes of the same step (measured): the
         // sphere-only variant runs at 6 waves per SIMD and is bound by vector-instruction issue, where two nested
         // branches cost fewer vector instructions than selects; the full variant (4 waves, box entries resolved in the
         // step) gains 7 % from a branch-free step.
-        if (FEAT == 0) {
+        if constexpr (PAIR) {
+            // One visit of a pair node: both children's boxes, the nearer hit child next, the other one pushed; nothing hit: pop.
+            if (phase == PH_TRAV) {
+                float tn_a, tn_b;
+                const bool hit_a = slab_child(n.a, c.sr, (float)far_bound, tn_a), hit_b = slab_child(n.b, c.sr, (float)far_bound, tn_b);
+                const bool b_first = hit_b && (!hit_a || tn_b < tn_a);
+                int first = b_first ? n.ref_b : n.ref_a;
+                const int second = b_first ? n.ref_a : n.ref_b;
+                if (hit_a && hit_b) { stack_lane[sp] = (int16_t)top; sp += BLOCK; top = second; }
+                else if (!hit_a && !hit_b) { first = top; sp -= BLOCK; top = (int)stack_lane[sp]; }
+                c.node = first;
+                if (first < 0) phase = first == kPairEnd ? PH_SHADE : PH_SPECIAL;  // a leaf parks the lane for the sphere batch
+            }
+        } else if (FEAT == 0) {
             if (phase == PH_TRAV) {
                 // (inner entries and the sentinel carry no flag bits: the tag is compared whole)
                 if (n.tag == TAG_INNER) c.node = slab_hit_any(n, c.sr, far_bound) ? c.node + 1 : n.link;
@@ -1534,7 +1619,7 @@ void mlrt_render_kernel(const KParams<real> P) {
             }
             phase = (trav && !handled) ? (kind == TAG_END ? PH_SHADE : PH_SPECIAL) : phase;
         }
-        n = fetch_entry(S, c.node, n_nodes);
+        if constexpr (PAIR) n = fetch_pair(S, c.node); else n = fetch_entry(S, c.node, n_nodes);
         }
         if (MLRT_STATS_ON(P)) { st_iter++; const unsigned long long t = __builtin_readcyclecounter(); st_c_trav += t - st_c0; st_c0 = t; }
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
@@ -1542,6 +1627,33 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
         if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= (FEAT == 0 ? MLRT_T_SPECIAL_LEAN : MLRT_T_SPECIAL) || m_trav == 0ull))) {
             if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int round = 0; round < MLRT_PAIR_SPECIAL_ROUNDS; round++) {
+                    if (round > 0 && __ballot(phase == PH_SPECIAL) == 0ull) break;
+                    if (phase == PH_SPECIAL) {
+                        // Sphere::hit of the leaf's primitive.  A hit at exactly the closest distance so far counts only from a primitive the
+                        // reference visits later (mlrt_device.hpp DPair): the result is independent of the device's visiting order.
+                        const int prim = c.node - kPairLeaf;
+                        const Ray r = local_ray<FEAT>(S, -1, o, d);
+                        double t;
+                        if (sphere_hit(pair_sphere(S, prim), r, 0.001, c.closest, t) && (t < c.closest || prim > c.hit_node)) { c.closest = t; c.hit_node = prim; }
+                        phase = PH_TRAV;
+                        if (depth & kPrimaryFlag) {  // next candidate of the tile's list, or done
+                            const int k = ((depth >> 16) & 0xFF) + 1;
+                            const int bank = pix >> kPixBankShift;
+                            if (k < cand[bank * kCandRecord]) { c.node = kPairLeaf + (int)cand[bank * kCandRecord + 1 + k]; depth += 1 << 16; phase = PH_SPECIAL; }
+                            else { c.node = kPairEnd; depth &= 0xFFFF; phase = PH_SHADE; }
+                        } else {
+                            const int next = top;
+                            sp -= BLOCK; top = (int)stack_lane[sp];
+                            c.node = next;
+                            if (next < 0) phase = next == kPairEnd ? PH_SHADE : PH_SPECIAL;
+                        }
+                    }
+                }
+                n = fetch_pair(S, c.node);
+            } else {
             if (phase == PH_SPECIAL) {
                 special_entry<FEAT>(S, n, c, o, d, g, key);
                 phase = PH_TRAV;
@@ -1553,6 +1665,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                 }
             }
             n = fetch_entry(S, c.node, n_nodes);
+            }
         }
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_special += t - st_c0; st_c0 = t; }
         // (C) batched shading, path termination and regeneration
@@ -1571,7 +1684,7 @@ void mlrt_render_kernel(const KParams<real> P) {
             bool have_turbulence = false;
             real turbulence = (real)0;
             if (kWaveNoise) {
-                if (hit) h = hit_attributes<FEAT>(S, c, o, d);
+                if (hit) h = hit_attributes<FEAT, PAIR>(S, c, o, d);
                 bool marble = false;
                 int table = 0;
                 float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -1591,11 +1704,11 @@ void mlrt_render_kernel(const KParams<real> P) {
             if (mine && has_path) {
                 if (MLRT_DEBUG_ON(P) && (int)g.pixel == P.debug_pixel && (int)g.sample == P.debug_sample)
                     printf("[mlrt dbg] depth %d hit_node %d tag %d xf %d t %.17g draw %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %g %g %g\n", depth, c.hit_node,
-                           c.hit_node >= 0 ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
+                           (c.hit_node >= 0 && !PAIR) ? S.nodes[c.hit_node].tag : -1, c.hit_xf, c.closest, g.draw, o.x, o.y, o.z, d.x, d.y, d.z, (double)thr.x, (double)thr.y, (double)thr.z);
                 V3 radiance = mk(0, 0, 0);
                 bool done = true;
                 if (hit) {
-                    if (!kWaveNoise) h = hit_attributes<FEAT>(S, c, o, d);
+                    if (!kWaveNoise) h = hit_attributes<FEAT, PAIR>(S, c, o, d);
                     V3 emitted = mk(0, 0, 0);
                     if (scatter<FEAT>(S, h, o, d, thr, emitted, g, key, P.max_depth - depth, have_turbulence, turbulence)) {
                         depth--;
@@ -1697,6 +1810,7 @@ void mlrt_render_kernel(const KParams<real> P) {
             if (mine) {
                 if (new_ray) {
                     c.node = 0; c.xf = -1; c.closest = (double)INFINITY; c.hit_node = -1; c.hit_aux = 0; c.hit_xf = -1;
+                    if (PAIR) { sp = BLOCK; top = kPairEnd; }  // the root node, an empty stack
                     Ray wr;
                     wr.o = o; wr.d = d;
                     c.sr = slab_ray(wr);
@@ -1705,8 +1819,8 @@ void mlrt_render_kernel(const KParams<real> P) {
                         const int bank = pix >> kPixBankShift;
                         const int count = cand[bank * kCandRecord];
                         if (count != kCandInvalid) {
-                            if (count > 0) { c.node = cand[bank * kCandRecord + 1]; depth |= kPrimaryFlag; phase = PH_SPECIAL; }
-                            else { c.node = n_nodes; phase = PH_SHADE; }  // nothing inside the tile's frustum: background
+                            if (count > 0) { c.node = (PAIR ? (int)kPairLeaf : 0) + (int)cand[bank * kCandRecord + 1]; depth |= kPrimaryFlag; phase = PH_SPECIAL; }
+                            else { c.node = PAIR ? (int)kPairEnd : n_nodes; phase = PH_SHADE; }  // nothing inside the tile's frustum: background
                         }
                     }
                 } else if (want) {
@@ -1714,7 +1828,7 @@ void mlrt_render_kernel(const KParams<real> P) {
                     phase = (queue_done && t_next >= t_total) ? PH_IDLE : PH_WAIT;
                 }  // else (max_depth == 0): the lane's sample is already finished; it stays in PH_SHADE and asks again
             }
-            n = fetch_entry(S, c.node, n_nodes);
+            if constexpr (PAIR) n = fetch_pair(S, c.node); else n = fetch_entry(S, c.node, n_nodes);
         }
         if (MLRT_STATS_ON(P)) { const unsigned long long t = __builtin_readcyclecounter(); st_c_shade += t - st_c0; }
         // The end of the loop, and watchdog (1).  No lane was traversing, parked for a batch or shading in this iteration:
@@ -1955,33 +2069,47 @@ __global__ void mlrt_probe_accumulate_kernel(int n, const double* radiance, unsi
 #endif
 namespace MLRT_NS {
 constexpr uint32_t kLeanFeatures = 0;
-template <bool LDS, uint32_t FEAT, int BLOCK>
+template <bool LDS, uint32_t FEAT, int BLOCK, bool PAIR = false>
 int launch_variant(const KParams<real>& P, int grid, size_t dyn_lds, hipStream_t stream) {
-    if (LDS) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlrt_render_kernel<LDS, FEAT, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    if (LDS || PAIR) {  // (the pair walk's stacks are dynamic LDS even when the scene stays in HBM)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlrt_render_kernel<LDS, FEAT, BLOCK, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((mlrt_render_kernel<LDS, FEAT, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), dyn_lds, stream, P);
+    hipLaunchKernelGGL((mlrt_render_kernel<LDS, FEAT, BLOCK, PAIR>), dim3((unsigned)grid), dim3(BLOCK), dyn_lds, stream, P);
     return (int)hipGetLastError();
 }
-template <bool LDS, uint32_t FEAT, int BLOCK>
+template <bool LDS, uint32_t FEAT, int BLOCK, bool PAIR = false>
 int occupancy_variant(size_t dyn_lds) {
     int blocks = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, mlrt_render_kernel<LDS, FEAT, BLOCK>, BLOCK, dyn_lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, mlrt_render_kernel<LDS, FEAT, BLOCK, PAIR>, BLOCK, dyn_lds);
     return e == hipSuccess ? blocks : -1;
+}
+// the pair-walk variant exists in the builds with f32 culling entries
+template <bool LDS>
+int launch_pair(const KParams<real>& P, int grid, size_t dyn_lds, hipStream_t stream) {
+    if constexpr (kCull32) return launch_variant<LDS, kLeanFeatures, MLRT_LEAN_BLOCK, true>(P, grid, dyn_lds, stream);
+    else return (int)hipErrorInvalidValue;
+}
+template <bool LDS>
+int occupancy_pair(size_t dyn_lds) {
+    if constexpr (kCull32) return occupancy_variant<LDS, kLeanFeatures, MLRT_LEAN_BLOCK, true>(dyn_lds);
+    else return -1;
 }
 }  // namespace MLRT_NS
 
-// variant: 0 = FULL, 1 = LEAN
+// variant: 0 = FULL, 1 = LEAN (threaded list), 2 = LEAN over the pair structure (KParams::pair_walk)
 extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream) {
     const mlrt::KParams<MLRT_NS::real>& P = *static_cast<const mlrt::KParams<MLRT_NS::real>*>(kparams);
     int rc;
     if (P.primary_lists) {
-        hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel, dim3((unsigned)(P.n_rows * ((P.tiles_per_row + 63) / 64))), dim3(64), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
+        const dim3 pgrid((unsigned)(P.n_rows * ((P.tiles_per_row + 63) / 64)));
+        if (variant == 2) hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel<true>, pgrid, dim3(64), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
+        else hipLaunchKernelGGL(MLRT_NS::mlrt_primary_lists_kernel<false>, pgrid, dim3(64), 0, stream, P, const_cast<uint16_t*>(P.primary_lists));
         rc = (int)hipGetLastError();
         if (rc != 0) return rc;
     }
-    if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
+    if (variant == 2) rc = lds_scene ? MLRT_NS::launch_pair<true>(P, grid, dyn_lds, stream) : MLRT_NS::launch_pair<false>(P, grid, dyn_lds, stream);
+    else if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
                                      : MLRT_NS::launch_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream);
     else rc = lds_scene ? MLRT_NS::launch_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream)
                         : MLRT_NS::launch_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream);
@@ -2002,11 +2130,13 @@ extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
     return 0;
 #endif
 }
-extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
-extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant == 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }
+extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant >= 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
+extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant >= 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }
+extern "C" int MLRT_CAT(mlrt_has_pair_walk_, MLRT_SUFFIX)(void) { return MLRT_NS::kCull32 ? 1 : 0; }
 extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(void) { return MLRT_NS::kAccBytesPerWave; }
 extern "C" int MLRT_CAT(mlrt_lds_frame_bytes_, MLRT_SUFFIX)(void) { return MLRT_NS::kFrameParamBytes; }
 extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene, size_t dyn_lds) {
+    if (variant == 2) return lds_scene ? MLRT_NS::occupancy_pair<true>(dyn_lds) : MLRT_NS::occupancy_pair<false>(dyn_lds);
     if (variant == 1) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds);
     return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds);
 }

@@ -49,7 +49,7 @@ def test_product_f64_colour_sums_equal_strict_f64(mlrt, earthmap, name, width, a
 
 
 SWITCHES = [dict(sah=0), dict(leaf_wrap=0), dict(sah=0, leaf_wrap=0), dict(primary_lists=0), dict(lds_scene=0), dict(force_full=1), dict(cull_f64=1),
-            dict(cull_f64=1, sah=0, leaf_wrap=0),
+            dict(cull_f64=1, sah=0, leaf_wrap=0), dict(pair_walk=0), dict(pair_walk=0, primary_lists=0), dict(pair_walk=0, sah=0, leaf_wrap=0), dict(lds_scene=0, primary_lists=0),
             dict(tile_samples=64, tile_queues=1), dict(tail=[64, 64, 128], tile_queues=64)]
 
 
@@ -66,6 +66,8 @@ def test_no_option_switch_changes_an_f64_colour_sum(mlrt, earthmap, name):
         _, acc, info = colour_sums(mlrt, w, cam, params, mlrt.PRECISION_FP64, rows, opts=mlrt.options(**sw))
         if sw.get("lds_scene") == 0:
             assert not info["lds_scene"]
+        if name == "random":  # a sphere-only world: the pair structure unless switched off (or another kernel variant / entry type is forced)
+            assert info["kernel_variant"] == ("lean-pair" if not (sw.get("pair_walk") == 0 or sw.get("force_full") or sw.get("cull_f64")) else ("full" if sw.get("force_full") else "lean-threaded"))
         assert np.array_equal(acc, base), (sw, int(np.sum(acc != base)))
     w.close()
 
@@ -86,7 +88,7 @@ def test_fast_build_switches_keep_the_image_within_its_tolerance(mlrt):
         r.close()
         if "cull_f64" in sw:
             continue  # (an FP64 option)
-        if any(k in sw for k in ("sah", "leaf_wrap")):
+        if any(k in sw for k in ("sah", "leaf_wrap", "pair_walk")):
             rmse = float(np.sqrt(np.mean((img - base).astype(np.float64) ** 2)) / 255.0)
             assert rmse < 2e-4, (sw, rmse)
         else:
