@@ -1460,7 +1460,9 @@ void mlrt_render_kernel(const KParams<real> P) {
     // (Measured and not kept: `top` stored and the row below it re-read by every lane after every step, so that neither push nor pop
     // waits for the LDS inside a step and the step has no branch but the outer one: 3 % slower in both builds - the visit is bound by
     // the instructions it issues, not by the pop's round trip.  Only traversing lanes fetching their next node: +0.5 %.  Two rounds of
-    // the sphere batch for lanes whose pop is another leaf: +2 %.)
+    // the sphere batch for lanes whose pop is another leaf: +2 %.  Metal / Dielectric hits - a fifth of `random`'s hits, a third of a
+    // shading batch's code - shaded in batches of their own once 8 / 16 / 24 such lanes wait: +8 / +10 / +14 %: a lane that waits costs
+    // more than the code its absence lets a batch skip.)
     int16_t* const stack_lane = reinterpret_cast<int16_t*>(acc_base + (BLOCK / 64) * kAccBytesPerWave + kFrameParamBytes) + threadIdx.x;
     int sp = BLOCK, top = kPairEnd;
 
