@@ -259,7 +259,8 @@ double mlrt_context_last_kernel_ms(mlrt_context* ctx);
  * threads per workgroup, workgroups launched. out[4]. */
 int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]);
 /* Which render-kernel variant the context's scene runs on: 0 = FULL (every feature), 1 = sphere-only scene over the threaded entry
- * list, 2 = sphere-only scene over the pair structure (mlrt_options.pair_walk).  Negative: NULL context. */
+ * list, 2 = sphere-only scene over the pair structure (mlrt_options.pair_walk), 3 .. = FULL compiled for a subset of the scene
+ * features (the smallest compiled superset of what the scene uses).  Negative: NULL context. */
 int32_t mlrt_context_kernel_variant(mlrt_context* ctx);
 
 /* ---- several GPUs of one node, one process --------------------------------------------------------

@@ -334,7 +334,7 @@ class Renderer:
         out = (C.c_int64 * 4)()
         _check(lib().mlrt_context_info(self.ctx, out))
         return {"blob_bytes": int(out[0]), "lds_scene": bool(out[1]), "block_threads": int(out[2]), "grid": int(out[3]),
-                "kernel_variant": {0: "full", 1: "lean-threaded", 2: "lean-pair"}.get(int(lib().mlrt_context_kernel_variant(self.ctx)), "?")}
+                "kernel_variant": (lambda v: {0: "full", 1: "lean-threaded", 2: "lean-pair"}.get(v, "full-subset-%d" % (v - 3)))(int(lib().mlrt_context_kernel_variant(self.ctx)))}
 
     def close(self):
         if getattr(self, "ctx", None):

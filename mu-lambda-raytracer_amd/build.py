@@ -30,7 +30,7 @@ TAG = os.environ.get("MLRT_TAG", "")
 EXTRA_KERNEL_FLAGS = os.environ.get("MLRT_KERNEL_FLAGS", "").split()
 EXTRA_KERNEL_FLAGS64 = os.environ.get("MLRT_KERNEL_FLAGS64", "").split()
 # the instrumented kernels need the registers the release kernels give up for occupancy: looser launch bounds
-DEBUG_FLAGS = ["-DMLRT_DEBUG_BUILD=1"] if DEBUG else []
+DEBUG_FLAGS = ["-DMLRT_DEBUG_BUILD=1", "-DMLRT_PER_VARIANT_SHAPES=0"] if DEBUG else []  # (one loose workgroup shape for every non-sphere-only variant)
 DEBUG_FLAGS_F32 = ["-DMLRT_LEAN_BLOCK=1024", "-DMLRT_LEAN_WAVES_PER_EU=4"] if DEBUG else []
 if DEBUG:
     os.environ.setdefault("MLRT_BLOCK", "768")

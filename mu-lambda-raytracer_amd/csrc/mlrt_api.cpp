@@ -17,13 +17,15 @@
 #include "mlrt_device.hpp"
 
 // One set of entry points per kernel build (mlrt_kernel.hip compiled with MLRT_SUFFIX = f32 | f64 | f64s).
-// variant: 0 = FULL (every feature), 1 = LEAN over the threaded list, 2 = LEAN over the pair structure (see mlrt_kernel.hip)
+// variant: 0 = FULL (every feature), 1 = LEAN over the threaded list, 2 = LEAN over the pair structure, 3 .. = FULL compiled for a subset
+// of the features (see mlrt_kernel.hip)
 #define MLRT_DECLARE_BUILD(sfx)                                                                                                    \
     int mlrt_launch_##sfx(const void* kparams, int variant, int lds_scene, int grid, size_t dyn_lds, hipStream_t stream);                \
     int mlrt_instrumented_##sfx(void);                                                                                             \
     uint32_t mlrt_variant_features_##sfx(int variant);                                                                             \
+    int mlrt_variant_count_##sfx(void);                                                                                            \
     int mlrt_block_threads_##sfx(int variant);                                                                                     \
-    int mlrt_acc_bytes_per_wave_##sfx(void);                                                                                       \
+    int mlrt_acc_bytes_per_wave_##sfx(int variant);                                                                                       \
     int mlrt_lds_frame_bytes_##sfx(void);                                                                                          \
     int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);                                                          \
     int mlrt_perlin_in_hbm_##sfx(void);                                                                                           \
@@ -55,20 +57,21 @@ struct KernelBuild {
     int (*instrumented)(void);
     uint32_t (*variant_features)(int);
     int (*block_threads)(int);
-    int (*acc_bytes_per_wave)(void);
+    int (*acc_bytes_per_wave)(int);
     int (*lds_frame_bytes)(void);
     int (*occupancy)(int, int, size_t);
     int (*probe)(int, const void*, int, const void*, const void*, void*, void*, int, hipStream_t);  // debug library only, else nullptr
     int (*perlin_in_hbm)(void);
     int (*lean_materials_in_hbm)(void);
     int (*has_pair_walk)(void);
+    int (*variant_count)(void);
 };
 #ifdef MLRT_DEBUG_BUILD
 #define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
 #else
 #define MLRT_PROBE_OF(sfx) nullptr
 #endif
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx, mlrt_has_pair_walk_##sfx}
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx, mlrt_has_pair_walk_##sfx, mlrt_variant_count_##sfx}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -843,7 +846,7 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, const m
 // stays small against the frame, and max_depth small enough for the list cursor the kernel keeps in the upper bits of a
 // lane's depth word (max_depth is any i32 in the reference: above 65535 the lanes simply walk the BVH).
 bool primary_lists_wanted(const mlrt_context* c, const mlrt_params* p) {
-    return c->variant >= 1 && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && (c->pair_walk ? c->n_prims : c->n_nodes) <= 4096 &&
+    return (c->variant == 1 || c->variant == 2) && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && (c->pair_walk ? c->n_prims : c->n_nodes) <= 4096 &&
            p->image_height < 65536 && p->max_depth <= 0xFFFF;
 }
 
@@ -871,7 +874,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
     TilePlan T;
-    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant >= 1, c->opt, T);
+    plan_tiles(p->image_width, n_rows, p->samples_per_pixel, (double)c->n_cus * c->blocks_per_cu * (c->block_threads / 64), c->variant == 1 || c->variant == 2, c->opt, T);
     MLRT_REQUIRE(T.n_tiles < ((int64_t)1 << 31), "too many tiles for the 32-bit tile counter");
     K.pix_per_tile = T.pix_per_tile; K.tiles_per_row = T.tiles_per_row; K.n_groups = T.n_groups; K.n_big = T.n_big; K.big = T.big; K.n_tail = T.n_tail;
     for (int k = 0; k <= mlrt::kMaxTailPasses; k++) K.tail_s0[k] = T.tail_s0[k];
@@ -880,9 +883,10 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.tiles_per_row_magic = T.tiles_per_row_magic; K.tiles_per_row_shift = T.tiles_per_row_shift;
     const int pix = T.pix_per_tile;
     {   // cut the wave's accumulator area (mlrt_kernel.hip kAccBytesPerWave) into banks: sums + remaining/out/values + candidate list
-        const int area = c->build->acc_bytes_per_wave();
+        const bool lean = c->variant == 1 || c->variant == 2;
+        const int area = c->build->acc_bytes_per_wave(c->variant);
         K.bank_values = 3 * pix;
-        K.n_banks = std::max(1, std::min(16, (area - 16 * (12 + 32)) / (K.bank_values * 8)));  // kMaxBanks x (3 ints + candidate record)
+        K.n_banks = std::max(1, std::min(16, (area - 16 * (12 + (lean ? 32 : 0))) / (K.bank_values * 8)));  // kMaxBanks x (3 ints + candidate record: sphere-only variants)
     }
     K.acc_global = c->d_acc;
     K.rgb_out = d_rgb; K.accum_out = d_accum;
@@ -1096,8 +1100,17 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         c->features = scene_features(*scene);
         const uint32_t lean = c->build->variant_features(1);
         c->variant = ((c->features & ~lean) == 0 && !options->force_full) ? 1 : 0;
+        if (c->variant == 0 && !options->force_full) {
+            // the FULL kernel compiled for the smallest superset of the scene's features (variant 0 has them all)
+            auto bits = [](uint32_t f) { int n = 0; for (; f; f &= f - 1) n++; return n; };
+            for (int v = 3; v < c->build->variant_count(); v++) {
+                const uint32_t f = c->build->variant_features(v);
+                if ((c->features & ~f) == 0 && bits(f) < bits(c->build->variant_features(c->variant))) c->variant = v;
+            }
+        }
         std::vector<unsigned char> blob;
-        const bool solid_only = c->variant == 1;  // the LEAN kernel variant reads no texture table (its scenes have SolidColor textures only)
+        // a kernel variant without texture features reads no texture table (its scenes have SolidColor textures only: the colour rides in the material)
+        const bool solid_only = (c->build->variant_features(c->variant) & (FEAT_TEX_IMAGE | FEAT_TEX_NOISE | FEAT_TEX_CHECKER)) == 0;
         c->block_threads = c->build->block_threads(c->variant);
         auto take = [&](auto& P) {
             blob.swap(P.blob);
@@ -1109,7 +1122,7 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         const bool wraps = !strict && options->leaf_wrap != 0, sah = !strict && options->sah != 0;
         // what of a blob of `bytes` (Perlin tables at `off_perlin`) must fit the LDS next to the waves' accumulators
         const size_t lds_limit = 160 * 1024;
-        const size_t lds_other = (size_t)(c->block_threads / 64) * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes();
+        const size_t lds_other = (size_t)(c->block_threads / 64) * (size_t)c->build->acc_bytes_per_wave(c->variant) + (size_t)c->build->lds_frame_bytes();
         auto fits_lds = [&](const auto& P) { return (size_t)(c->build->perlin_in_hbm() ? P.off_perlin_vec : (int32_t)P.blob.size()) + lds_other <= lds_limit; };
         // Sphere-only scenes: the pair structure (mlrt_device.hpp DPair) when the build has the walk, the spheres fit its 16-bit
         // references and the lanes' stacks fit the LDS; otherwise the threaded list below.
@@ -1192,10 +1205,10 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         // LDS plan: the blob is staged in LDS when it fits next to the per-wave accumulators and the frame parameters
         // (the strict build is a test instrument: small workgroups reading the blob through L2)
         const int waves = c->block_threads / 64;
-        const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave() + (size_t)c->build->lds_frame_bytes() + pair_stack_bytes;
+        const size_t acc = (size_t)waves * (size_t)c->build->acc_bytes_per_wave(c->variant) + (size_t)c->build->lds_frame_bytes() + pair_stack_bytes;
         // (f64 builds read the Perlin tables - the blob's tail - from HBM: they alone would keep final_scene's blob out of LDS)
         c->lds_blob_bytes = c->build->perlin_in_hbm() ? c->off[3] : (int32_t)blob.size();
-        if (c->variant >= 1 && c->build->lean_materials_in_hbm()) c->lds_blob_bytes = c->off[1];  // entries only (the blob starts with them)
+        if ((c->variant == 1 || c->variant == 2) && c->build->lean_materials_in_hbm()) c->lds_blob_bytes = c->off[1];  // entries only (the blob starts with them)
         c->lds_scene = !strict && (size_t)c->lds_blob_bytes + acc <= lds_limit && options->lds_scene != 0;
         c->dyn_lds = (c->lds_scene ? (size_t)c->lds_blob_bytes : 0) + acc;
         const int occ = c->build->occupancy(c->variant, c->lds_scene, c->dyn_lds);
@@ -1345,7 +1358,7 @@ void scene_params(const mlrt_context* c, uint64_t seed, KParams<R>& K) {
 template <typename F>
 void probe_launch(mlrt_context* c, int kind, uint64_t seed, int n, const void* a, const void* b, void* out, void* out2, int iarg, F&& with) {
     if (!c->build->probe) throw Fail{MLRT_ERR_UNSUPPORTED, "the directed probes exist in the debug build of the library only (build.py --debug)"};
-    MLRT_REQUIRE(c->variant == 0, "probes need the FULL packing of the scene: create the context with options.force_full = 1");
+    MLRT_REQUIRE(c->variant == 0 || c->variant >= 3, "probes need the FULL packing of the scene: create the context with options.force_full = 1");
     MLRT_HIP(hipSetDevice(c->device));
     int rc;
     if (c->precision == MLRT_PRECISION_FP32) {

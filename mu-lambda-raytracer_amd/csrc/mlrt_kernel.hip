@@ -48,6 +48,16 @@
 #define MLRT_BLOCK 512
 #endif
 #define DEV __device__ __forceinline__
+// Cold code kept OUT of line: sphere_uv's f64 acos / atan2 (0.07 texel fetches per sample of final_scene, none in most scenes) run for
+// a few lanes in a few shading batches, but inlined their registers are the kernel's: the f64 FULL variant needs 255 VGPRs with them
+// inline and 200 without (a kernel with an image texture alone: 193 / 129).  Out of line they cost a call and 32 bytes of stack for
+// callee-saved registers when they run.  (Perlin turbulence out of line made things worse: it takes the scene view by reference, which
+// then lives in memory: 157 -> 178 VGPRs for a noise-only kernel.)  -DMLRT_COLD_UV_INLINE puts it back (experiments).
+#ifdef MLRT_COLD_UV_INLINE
+#define MLRT_COLD_UV DEV
+#else
+#define MLRT_COLD_UV __device__ __attribute__((noinline))
+#endif
 // Branch weights for the register allocator: the traversal step runs every iteration of the kernel loop, the batches every
 // ~10th, a tile is opened every ~500th.  Without them a value the step reads (the slab ray) is as good a spill candidate
 // as one only the shading code reads, and at 80 registers the difference is 2x in frame time.
@@ -110,6 +120,10 @@ constexpr double kCullSlack64 = 1.0 + 1e-12;
 // banks, four-pixel tiles 6.  Many banks matter with small tiles: one 50-bounce path holds its bank while the other
 // lanes finish ~8 tiles' worth of 64-sample tiles.
 constexpr int kAccBytesPerWave = 1344;
+// The variants other than the sphere-only one have no candidate records (kMaxBanks x kCandRecord u16 = 512 bytes of the area): with the
+// smaller area final_scene's f64 entries stay LDS resident under a 768-thread workgroup (3 waves per SIMD).
+constexpr int kAccBytesPerWaveFull = 1344 - 512;
+constexpr int acc_bytes_per_wave(uint32_t feat) { return feat == 0 ? kAccBytesPerWave : kAccBytesPerWaveFull; }
 constexpr int kMaxBanks = 16;
 // + per bank: the tile's primary candidate list (count, then up to kCand entry indices as u16; count 0xFF = not usable)
 constexpr int kCand = 14;
@@ -960,7 +974,7 @@ DEV real reflectance(real cos_theta, real refraction_ratio) {  // materials.rs:8
     const real x2 = x * x;
     return r0_sq + ((real)1 - r0_sq) * (x * (x2 * x2));  // powi(5)
 }
-DEV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
+MLRT_COLD_UV void sphere_uv(V3 n, real& u, real& v) {  // shapes.rs:44-56
     const double pi = 3.14159265358979323846264338327950288;
     if (kFast) {
         const float theta = acosf(-(float)n.y);
@@ -1079,15 +1093,22 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
     return h;
 }
 // `turbulence`: the NoiseTexture turbulence of the hit point when the batch has already evaluated it (have_turbulence).
+// The colour a material's texture contributes at the hit (Lambertian / Isotropic albedo, DiffuseLight emission; materials.rs:25-34, 119-127,
+// volumes.rs:77-83): evaluated BEFORE scatter, while only the hit attributes are live - inside scatter's branches the Perlin code's
+// registers came on top of the sampler's and the new ray's.
 template <uint32_t FEAT>
-DEV bool scatter(const Scene& S, const HitAttr& h, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key, int bounce, bool have_turbulence, real turbulence) {
+DEV V3 material_texture(const Scene& S, const HitAttr& h, bool have_turbulence, real turbulence) {
+    const int kind = h.m.kind & 0xFF;
+    if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_NOISE | FEAT_TEX_CHECKER)) == 0 || kind == MLRT_MAT_METAL || kind == MLRT_MAT_DIELECTRIC) return ld3(h.m.albedo);
+    return texture_value<FEAT>(S, h.m.tex, ld3(h.m.albedo), h.u, h.v, to_v3(h.p), have_turbulence, turbulence);
+}
+template <uint32_t FEAT>
+DEV bool scatter(const Scene& S, const HitAttr& h, V3 texture_colour, P3& o, P3& d, V3& thr, V3& emitted, Rng& g, RngKey key, int bounce) {
     const P3 p = h.p;
     const V3 normal = h.normal;
-    const real u = h.u, v = h.v;
     const bool front_face = h.front_face;
     const DMaterial<real> m = h.m;
     const V3 dw = to_v3(d);  // world direction in shading precision
-    const V3 pf = to_v3(p);
     const int mk_kind = m.kind & 0xFF;
     // Lambertian, Metal and Isotropic all begin their RNG use with one random_in_unit_sphere (materials.rs:27,54,
     // volumes.rs:79) and Dielectric may draw one word: the scatter's block, evaluated once for the whole batch.
@@ -1101,7 +1122,7 @@ DEV bool scatter(const Scene& S, const HitAttr& h, P3& o, P3& d, V3& thr, V3& em
         V3 dir = normal + s;
         const real eps = (real)1e-8;
         if (abs_r(dir.x) < eps && abs_r(dir.y) < eps && abs_r(dir.z) < eps) dir = normal;
-        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);
+        thr = thr * texture_colour;
         o = p; d = to_p3(dir);
         return true;
     }
@@ -1134,11 +1155,11 @@ DEV bool scatter(const Scene& S, const HitAttr& h, P3& o, P3& d, V3& thr, V3& em
     }
     if ((FEAT & FEAT_MEDIUM) && mk_kind == MLRT_MAT_ISOTROPIC) {  // volumes.rs:77-83
         const V3 dir = s;
-        thr = thr * texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);
+        thr = thr * texture_colour;
         o = p; d = to_p3(dir);
         return true;
     }
-    emitted = texture_value<FEAT>(S, m.tex, ld3(m.albedo), u, v, pf, have_turbulence, turbulence);  // DiffuseLight, materials.rs:119-127
+    emitted = texture_colour;  // DiffuseLight, materials.rs:119-127
     return false;
 }
 
@@ -1407,8 +1428,32 @@ DEV unsigned int* watchdog_record() {
 #ifndef MLRT_FULL_WAVES_PER_EU
 #define MLRT_FULL_WAVES_PER_EU 1
 #endif
+// Workgroup shapes of the variants that are not sphere-only, by what their code needs in registers (tools/kernel_resources.py): waves per
+// SIMD the register allocator is held to, and threads per workgroup (waves per SIMD x 256, split over two workgroups per CU above 1024
+// threads - their scenes are small).  The strict and cull_f64 builds keep one shape (MLRT_BLOCK, MLRT_FULL_WAVES_PER_EU).
+//   f32:  image only 79 VGPRs -> 6 waves (2 x 768: earth 5.6 -> 5.2 ms); everything else 4 waves (1024).  (cornell_box / cornell_smoke / checker
+//         need 89 - 93 VGPRs, but held to the 96 of 5 waves, 2 x 640 threads, they lose: cornell_box 18.9 -> 24.1 ms, cornell_smoke 30.5 -> 38.4)
+//   f64:  cornell_box 129 -> held to 128: 4 waves (1024); image only 128 -> 4; the rest 137 - 196 -> held to 168: 3 waves (768):
+//         cornell_box 37.5 -> 28.1 ms, cornell_smoke 57.6 -> 46.6, final_scene (spp 200) 124.8 -> 109.4 against 512 threads at 2 waves
+#ifndef MLRT_PER_VARIANT_SHAPES
+#define MLRT_PER_VARIANT_SHAPES 1
+#endif
+constexpr bool kShaped = MLRT_PER_VARIANT_SHAPES != 0 && kCull32 && !kStrict;
+constexpr int full_waves(uint32_t feat) {
+    if (!kShaped) return MLRT_FULL_WAVES_PER_EU;
+    const bool noise = (feat & FEAT_TEX_NOISE) != 0;
+    const bool geometry = (feat & (FEAT_BOX | FEAT_RECT | FEAT_XFORM | FEAT_MEDIUM)) != 0;
+    if (kFast) return (feat == FEAT_TEX_IMAGE && !geometry && !noise) ? 6 : 4;
+    if (feat == (FEAT_BOX | FEAT_RECT | FEAT_XFORM) || (feat == FEAT_TEX_IMAGE && !geometry)) return 4;
+    return 3;
+}
+constexpr int full_block(uint32_t feat) {
+    if (!kShaped) return MLRT_BLOCK;
+    const int w = full_waves(feat);
+    return w <= 4 ? w * 256 : w * 128;  // above 4 waves per SIMD: two workgroups per CU
+}
 template <bool LDS_SCENE, uint32_t FEAT, int BLOCK, bool PAIR = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0 ? MLRT_LEAN_WAVES_PER_EU : MLRT_FULL_WAVES_PER_EU)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0 ? MLRT_LEAN_WAVES_PER_EU : full_waves(FEAT))))
 void mlrt_render_kernel(const KParams<real> P) {
     static_assert(!PAIR || (FEAT == 0 && kCull32), "the pair walk serves sphere-only scenes in the builds with f32 culling");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1429,7 +1474,8 @@ void mlrt_render_kernel(const KParams<real> P) {
         base = P.blob;
         acc_base = smem;
     }
-    FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytesPerWave);
+    constexpr int kAccBytes = acc_bytes_per_wave(FEAT);
+    FrameParams& F = *reinterpret_cast<FrameParams*>(acc_base + (BLOCK / 64) * kAccBytes);
     if (threadIdx.x < 21) (&F.cam_origin[0])[threadIdx.x] = (&P.cam_origin[0])[threadIdx.x];  // cam_origin ... inv_hm1 are contiguous in both structs
     frame_reciprocals(P, F);
     if (threadIdx.x < 3) {
@@ -1463,15 +1509,15 @@ void mlrt_render_kernel(const KParams<real> P) {
     // the sphere batch for lanes whose pop is another leaf: +2 %.  Metal / Dielectric hits - a fifth of `random`'s hits, a third of a
     // shading batch's code - shaded in batches of their own once 8 / 16 / 24 such lanes wait: +8 / +10 / +14 %: a lane that waits costs
     // more than the code its absence lets a batch skip.)
-    int16_t* const stack_lane = reinterpret_cast<int16_t*>(acc_base + (BLOCK / 64) * kAccBytesPerWave + kFrameParamBytes) + threadIdx.x;
+    int16_t* const stack_lane = reinterpret_cast<int16_t*>(acc_base + (BLOCK / 64) * kAccBytes + kFrameParamBytes) + threadIdx.x;
     int sp = BLOCK, top = kPairEnd;
 
     const int n_banks = P.n_banks, bank_vals = P.bank_values;  // wave-uniform
-    int* bank_remaining = reinterpret_cast<int*>(acc_base + wave * kAccBytesPerWave);  // samples of the bank's tile not yet finished
+    int* bank_remaining = reinterpret_cast<int*>(acc_base + wave * kAccBytes);  // samples of the bank's tile not yet finished
     int* bank_out = bank_remaining + kMaxBanks;                                         // first index into acc_global
     int* bank_values = bank_remaining + 2 * kMaxBanks;                                  // npix * 3
-    uint16_t* cand = reinterpret_cast<uint16_t*>(bank_remaining + 3 * kMaxBanks);       // [kMaxBanks][kCandRecord]: the tile's primary candidates
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(cand + kMaxBanks * kCandRecord);  // [n_banks][bank_vals]
+    uint16_t* cand = reinterpret_cast<uint16_t*>(bank_remaining + 3 * kMaxBanks);       // [kMaxBanks][kCandRecord]: the tile's primary candidates (sphere-only variants)
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(cand + (FEAT == 0 ? kMaxBanks * kCandRecord : 0));  // [n_banks][bank_vals]
     const RngKey key = {P.seed_lo, P.seed_hi};
     const int n_nodes = P.n_nodes;
 
@@ -1712,7 +1758,8 @@ void mlrt_render_kernel(const KParams<real> P) {
                 if (hit) {
                     if (!kWaveNoise) h = hit_attributes<FEAT, PAIR>(S, c, o, d);
                     V3 emitted = mk(0, 0, 0);
-                    if (scatter<FEAT>(S, h, o, d, thr, emitted, g, key, P.max_depth - depth, have_turbulence, turbulence)) {
+                    const V3 texture_colour = material_texture<FEAT>(S, h, have_turbulence, turbulence);
+                    if (scatter<FEAT>(S, h, texture_colour, o, d, thr, emitted, g, key, P.max_depth - depth)) {
                         depth--;
                         if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
                     } else {
@@ -1947,7 +1994,7 @@ __global__ void mlrt_probe_rays_kernel(const KParams<real> P, int n, const doubl
     r[8] = (double)h.u; r[9] = (double)h.v; r[10] = h.front_face ? 1.0 : 0.0;
     V3 thr = mk(1, 1, 1), emitted = mk(0, 0, 0);
     const int bounce = (int)((g.draw + 3u) >> 2) - 1;  // (the block rule of scenes without media: block = 1 + bounce)
-    const bool scattered = scatter<FEAT>(S, h, o, d, thr, emitted, g, key, bounce, false, (real)0);
+    const bool scattered = scatter<FEAT>(S, h, material_texture<FEAT>(S, h, false, (real)0), o, d, thr, emitted, g, key, bounce);
     r[11] = scattered ? 1.0 : 0.0;
     if (scattered) {
         r[12] = o.x; r[13] = o.y; r[14] = o.z; r[15] = d.x; r[16] = d.y; r[17] = d.z;
@@ -2071,6 +2118,15 @@ __global__ void mlrt_probe_accumulate_kernel(int n, const double* radiance, unsi
 #endif
 namespace MLRT_NS {
 constexpr uint32_t kLeanFeatures = 0;
+// Variants 3 .. 3 + kSubsets - 1: the FULL kernel compiled for a subset of the scene features (mlrt_device.hpp FEAT_*) - the dead branches
+// of the others leave the loop and the registers they held with them.  One per reference world that is not sphere-only, by what its
+// builder creates (worlds.rs): cornell_box (:244-290), cornell_smoke (:292-338), final_scene (:368-469: everything but a Checker),
+// earth (:165-189), simple_light (:214-242), debug_perlin (:191-212), two_spheres / random_chk (:115-163).  The host picks the
+// smallest compiled superset of a scene's features (variant 0 = all of them).
+constexpr int kSubsets = 7;
+constexpr uint32_t kSubsetFeatures[kSubsets] = {
+    FEAT_BOX | FEAT_RECT | FEAT_XFORM, FEAT_BOX | FEAT_RECT | FEAT_XFORM | FEAT_MEDIUM, FEAT_ALL & ~FEAT_TEX_CHECKER,
+    FEAT_TEX_IMAGE, FEAT_RECT | FEAT_TEX_NOISE, FEAT_TEX_NOISE, FEAT_TEX_CHECKER};
 template <bool LDS, uint32_t FEAT, int BLOCK, bool PAIR = false>
 int launch_variant(const KParams<real>& P, int grid, size_t dyn_lds, hipStream_t stream) {
     if (LDS || PAIR) {  // (the pair walk's stacks are dynamic LDS even when the scene stays in HBM)
@@ -2113,8 +2169,12 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
     if (variant == 2) rc = lds_scene ? MLRT_NS::launch_pair<true>(P, grid, dyn_lds, stream) : MLRT_NS::launch_pair<false>(P, grid, dyn_lds, stream);
     else if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
                                      : MLRT_NS::launch_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream);
-    else rc = lds_scene ? MLRT_NS::launch_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream)
-                        : MLRT_NS::launch_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(P, grid, dyn_lds, stream);
+#define MLRT_SUBSET_LAUNCH(k) else if (variant == 3 + k) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kSubsetFeatures[k], MLRT_NS::full_block(MLRT_NS::kSubsetFeatures[k])>(P, grid, dyn_lds, stream) \
+                                                                         : MLRT_NS::launch_variant<false, MLRT_NS::kSubsetFeatures[k], MLRT_NS::full_block(MLRT_NS::kSubsetFeatures[k])>(P, grid, dyn_lds, stream);
+    MLRT_SUBSET_LAUNCH(0) MLRT_SUBSET_LAUNCH(1) MLRT_SUBSET_LAUNCH(2) MLRT_SUBSET_LAUNCH(3) MLRT_SUBSET_LAUNCH(4) MLRT_SUBSET_LAUNCH(5) MLRT_SUBSET_LAUNCH(6)
+#undef MLRT_SUBSET_LAUNCH
+    else rc = lds_scene ? MLRT_NS::launch_variant<true, mlrt::FEAT_ALL, MLRT_NS::full_block(mlrt::FEAT_ALL)>(P, grid, dyn_lds, stream)
+                        : MLRT_NS::launch_variant<false, mlrt::FEAT_ALL, MLRT_NS::full_block(mlrt::FEAT_ALL)>(P, grid, dyn_lds, stream);
     if (rc != 0) return rc;
     {
         const int n = P.n_rows * P.width * 3;
@@ -2132,15 +2192,24 @@ extern "C" int MLRT_CAT(mlrt_instrumented_, MLRT_SUFFIX)(void) {
     return 0;
 #endif
 }
-extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) { return variant >= 1 ? MLRT_NS::kLeanFeatures : mlrt::FEAT_ALL; }
-extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) { return variant >= 1 ? MLRT_LEAN_BLOCK : MLRT_BLOCK; }
+extern "C" int MLRT_CAT(mlrt_variant_count_, MLRT_SUFFIX)(void) { return 3 + MLRT_NS::kSubsets; }
+extern "C" uint32_t MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(int variant) {
+    if (variant == 1 || variant == 2) return MLRT_NS::kLeanFeatures;
+    return (variant >= 3 && variant < 3 + MLRT_NS::kSubsets) ? MLRT_NS::kSubsetFeatures[variant - 3] : mlrt::FEAT_ALL;
+}
+extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) {
+    return (variant == 1 || variant == 2) ? MLRT_LEAN_BLOCK : MLRT_NS::full_block(MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(variant));
+}
 extern "C" int MLRT_CAT(mlrt_has_pair_walk_, MLRT_SUFFIX)(void) { return MLRT_NS::kCull32 ? 1 : 0; }
-extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(void) { return MLRT_NS::kAccBytesPerWave; }
+extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(int variant) { return MLRT_NS::acc_bytes_per_wave(MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(variant)); }
 extern "C" int MLRT_CAT(mlrt_lds_frame_bytes_, MLRT_SUFFIX)(void) { return MLRT_NS::kFrameParamBytes; }
 extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene, size_t dyn_lds) {
     if (variant == 2) return lds_scene ? MLRT_NS::occupancy_pair<true>(dyn_lds) : MLRT_NS::occupancy_pair<false>(dyn_lds);
     if (variant == 1) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(dyn_lds);
-    return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_BLOCK>(dyn_lds);
+#define MLRT_SUBSET_OCC(k) if (variant == 3 + k) return lds_scene ? MLRT_NS::occupancy_variant<true, MLRT_NS::kSubsetFeatures[k], MLRT_NS::full_block(MLRT_NS::kSubsetFeatures[k])>(dyn_lds) : MLRT_NS::occupancy_variant<false, MLRT_NS::kSubsetFeatures[k], MLRT_NS::full_block(MLRT_NS::kSubsetFeatures[k])>(dyn_lds);
+    MLRT_SUBSET_OCC(0) MLRT_SUBSET_OCC(1) MLRT_SUBSET_OCC(2) MLRT_SUBSET_OCC(3) MLRT_SUBSET_OCC(4) MLRT_SUBSET_OCC(5) MLRT_SUBSET_OCC(6)
+#undef MLRT_SUBSET_OCC
+    return lds_scene ? MLRT_NS::occupancy_variant<true, mlrt::FEAT_ALL, MLRT_NS::full_block(mlrt::FEAT_ALL)>(dyn_lds) : MLRT_NS::occupancy_variant<false, mlrt::FEAT_ALL, MLRT_NS::full_block(mlrt::FEAT_ALL)>(dyn_lds);
 }
 
 #ifdef MLRT_DEBUG_BUILD
