@@ -68,10 +68,10 @@ def cpu_baseline(cfg, cam19, height, seconds_budget=15.0):
         earth = pkg.load_earthmap()
     ow = oracle.world(cfg["world"], cfg["seed"], earth)
     try:
-        threads = len(os.sched_getaffinity(0))
+        available = len(os.sched_getaffinity(0))
     except AttributeError:
-        threads = os.cpu_count() or 1
-    threads = max(1, min(threads, 32))
+        available = os.cpu_count() or 1
+    threads = max(1, available)  # every core this process may run on (the reference's rayon pool does the same: raytrace.rs:176)
     w, spp = cfg["image_width"], cfg["samples_per_pixel"]
     us = CPU_US_PER_SAMPLE.get(cfg["world"], 5.0)
     sample_budget = seconds_budget * threads / (us * 1e-6)
@@ -84,15 +84,18 @@ def cpu_baseline(cfg, cam19, height, seconds_budget=15.0):
     _, _, stats, secs = ow.render(cam19, w, height, spp_cpu, seed=cfg["seed"], rng_mode=oracle_binding.RNG_PCG_ROW, rows=rows, threads=threads)
     ow.close()
     samples = len(rows) * w * spp_cpu
-    return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": threads, "cores_available": available, "kind": "port",
             "sample": "%d evenly spaced rows of the %dx%d image at spp %d%s (%.1f Msamples, %.1f s), PCG64 row streams, f64 C++ restatement of the Rust reference"
                       % (len(rows), w, height, spp_cpu, "" if spp_cpu == spp else " (config: %d; cost is linear in spp)" % spp, samples / 1e6, secs),
             "stats_per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"}}
 
 
+PROFILE_ROUND = "r03"
+
+
 def load_profile(config, dtype):
-    """The committed PMC summary for this (config, dtype): profiles/r02_pmc_<config>_<dtype>.json (tools/gpu_pmc.sh)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s_%s.json" % (config, dtype))
+    """The committed PMC summary for this (config, dtype): profiles/r03_pmc_<config>_<dtype>.json (tools/gpu_pmc.sh)."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%s.json" % (PROFILE_ROUND, config, dtype))
     if not os.path.exists(path):
         return None, None
     try:
@@ -101,19 +104,38 @@ def load_profile(config, dtype):
         return None, None
 
 
+def build_stamp():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from build_stamp import stamp
+        return stamp()
+    except Exception:
+        return None
+
+
 def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
     prof, prof_path = load_profile(config, dtype)
     out = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64 VALU instructions)", "frac": None, "traffic": None,
            "profile": prof_path, "kernel_ms": kernel_ms,
-           "peak_note": "1 wave-instruction / 2 cycles / SIMD-32 x %d SIMDs x %.1f GHz; f64 arithmetic issues at half that rate and transcendentals at "
-                        "1/4 (f32) to 1/8 (f64) of it (tools/microbench/valu_issue.hip, profiles/r02_valu_issue_microbench.txt), so 1.0 is not reachable by "
-                        "this instruction mix" % (SIMDS, CLOCK_GHZ)}
+           "peak_note": "1 wave-instruction / 2 cycles / SIMD-32 x %d SIMDs x %.1f GHz (MI355X_MICROARCH.md); what single instruction classes sustain "
+                        "against it: tools/microbench/valu_issue.hip, profiles/r03_valu_issue_microbench.txt" % (SIMDS, CLOCK_GHZ)}
     if prof:
         per_sample = prof["valu_insts_per_sample"]
         achieved = per_sample * my_samples / (kernel_ms * 1e-3) / 1e9
         out.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_insts_per_sample": per_sample,
                     "lane_utilisation": prof.get("lane_utilisation"), "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
                     "profile_frac_at_capture": prof.get("valu_issue_frac"), "traffic": prof.get("hbm_bytes_per_launch")})
+        if prof.get("lane_utilisation"):
+            # issue slots that carried work: frac x the share of lanes active in an issued instruction; and the lane-level instruction
+            # count per sample, which falls when instructions are removed and does NOT rise when idle lanes are added
+            out["useful_frac"] = out["frac"] * prof["lane_utilisation"]
+            out["valu_lane_insts_per_sample"] = per_sample * 64.0 * prof["lane_utilisation"]
+        # the committed counters describe the build they were captured on: compare with the library about to be timed
+        here, there = build_stamp(), prof.get("build_stamp")
+        out["profile_build"] = there
+        out["profile_stale"] = (not here) or (not there) or here.get("lib_sha256") != there.get("lib_sha256")
+        if out["profile_stale"] and here and there and here.get("source_sha256") == there.get("source_sha256"):
+            out["profile_stale_note"] = "the library was rebuilt from the same sources the profile was captured on"
         if prof.get("hbm_bytes_per_launch"):
             out["hbm_physical_GBps"] = prof["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
             out["hbm_physical_frac"] = out["hbm_physical_GBps"] / HBM_PEAK_GBS
@@ -126,6 +148,100 @@ def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
     return out
 
 
+def end_to_end(pkg, torch, cfg, world, cam, params, precision, dev, W, H, spp):
+    """The reference's own timing window (/root/reference/src/main.rs:145-174: renderer construction + render()), which for the device path
+    is context creation (validate + SAH + pack + upload), the first frame and the download of the image - measured once each, outside the
+    timed region - and the same window as the CLI reports it (`mlrt ... > /dev/null`: "Rendered in X s" on stderr, process start excluded)."""
+    import subprocess
+    rec = {}
+    try:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        renderer = pkg.Renderer(world, cam, params, precision=precision, device=dev.index or 0)
+        t1 = time.perf_counter()
+        d_rgb = torch.zeros((H, W, 3), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        renderer.render_device(None, H, d_rgb.data_ptr(), None, None)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        host = d_rgb.cpu()
+        t4 = time.perf_counter()
+        renderer.close()
+        del host
+        rec.update({"context_create_ms": (t1 - t0) * 1e3, "first_frame_ms": (t3 - t2) * 1e3, "d2h_ms": (t4 - t3) * 1e3,
+                    "window_ms": (t1 - t0 + t3 - t2 + t4 - t3) * 1e3, "window_Msamples_per_s": W * H * spp / (t1 - t0 + t3 - t2 + t4 - t3) / 1e6})
+        # the blocking host-buffer form of the ABI (mlrt_context_render: allocations, kernels, download), second call = steady state
+        renderer = pkg.Renderer(world, cam, params, precision=precision, device=dev.index or 0)
+        renderer.render()
+        t5 = time.perf_counter()
+        renderer.render()
+        rec["host_render_ms"] = (time.perf_counter() - t5) * 1e3
+        renderer.close()
+    except Exception as e:  # noqa: BLE001 - a diagnostic record must not take the bench line down
+        rec["error"] = repr(e)
+    try:
+        cli = [pkg.CLI_PATH, "--world=" + cfg["world"], "--seed=%d" % cfg["seed"], "--aspect_ratio=" + cfg["aspect_ratio"], "--image_width=%d" % W,
+               "--samples_per_pixel=%d" % spp, "--precision=" + ("fp64" if precision == pkg.PRECISION_FP64 else "fp32"), "--format=p6"]
+        if cfg["aperture"]:
+            cli += ["--aperture=%g" % cfg["aperture"], "--focus_dist=%g" % cfg["focus_dist"]]
+        if cfg["world"] in ("earth", "final_scene"):
+            cli += ["--earthmap=" + pkg.EARTHMAP_PPM]
+        t0 = time.perf_counter()
+        r = subprocess.run(cli, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+        wall = time.perf_counter() - t0
+        line = [ln for ln in r.stderr.decode(errors="replace").splitlines() if "Rendered in" in ln]
+        if r.returncode == 0 and line:
+            secs = float(line[-1].split("Rendered in")[1].strip().rstrip("s"))
+            rec["cli"] = {"rendered_in_s": secs, "Msamples_per_s": W * H * spp / secs / 1e6, "process_wall_s": wall, "command": " ".join(os.path.basename(c) if i == 0 else c for i, c in enumerate(cli))}
+        else:
+            rec["cli"] = {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-200:])}
+    except Exception as e:  # noqa: BLE001
+        rec["cli"] = {"error": repr(e)}
+    return rec
+
+
+def main_inproc(args, cfg):
+    """--multi inproc: the product's own multi-device path (mlrt_multi_create / mlrt_multi_render, csrc/mlrt_multi.cpp) from ONE process:
+    rows dealt to the devices round-robin, one RCCL gather to devices[0], the image returned in host memory.  A step = one
+    mlrt_multi_render call (so, unlike the per-rank mode, the download of the image is inside the timed region)."""
+    import numpy as np
+    pkg = importlib.import_module("mu-lambda-raytracer_amd")
+    n_dev = pkg.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    if args.gpus > n_dev:
+        raise SystemExit("bench.py --multi inproc --gpus %d: only %d device(s) visible" % (args.gpus, n_dev))
+    W, spp = cfg["image_width"], cfg["samples_per_pixel"]
+    H = pkg.image_height(W, cfg["aspect"])
+    world = pkg.World(cfg["world"], cfg["seed"])
+    cam = pkg.default_camera(world, cfg["aspect"], cfg["aperture"], cfg["focus_dist"])
+    params = pkg.make_params(world, W, H, spp, cfg["max_depth"])
+    prec = pkg.PRECISION_FP64 if args.precision == "fp64" else pkg.PRECISION_FP32
+    multi = pkg.MultiRenderer(world, cam, params, list(range(args.gpus)), precision=prec)
+    for _ in range(args.warmup):
+        multi.render()
+    frame_ms, kernel_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        multi.render()
+        info = multi.info()
+        frame_ms.append(info["frame_ms"]); kernel_ms.append(info["kernel_ms"])
+    elapsed = time.perf_counter() - t0
+    multi.close()
+    world.close()
+    value = W * H * spp * args.steps / elapsed / 1e6
+    out = {"metric": cfg["metric"], "value": value, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
+           "config": {"workload": "--world=%s --seed=%d --aspect_ratio=%s --image_width=%d --samples_per_pixel=%d (BASELINE.json %s)"
+                                  % (cfg["world"], cfg["seed"], cfg["aspect_ratio"], W, spp, cfg["baseline"]),
+                      "parallelism": "inproc: mlrt_multi_render over devices 0..%d of one process, rows round-robin, one gather (%s), image returned in host memory"
+                                     % (args.gpus - 1, {1: "RCCL", 2: "hipMemcpyPeer"}.get(info["gather"], "?")),
+                      "frame_ms_mean": float(np.mean(frame_ms)), "kernel_ms_per_device_mean": [float(x) for x in np.mean(np.array(kernel_ms), axis=0)]}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +251,10 @@ def main():
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"], help="the headline mode (default: the reference's precision)")
     ap.add_argument("--no-fast", action="store_true", help="skip the fast (f32) sub-record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", default="ranks", choices=["ranks", "inproc"],
+                    help="ranks (default): one process per GPU (torch.distributed.run); inproc: ONE process drives --gpus devices through the C ABI's "
+                         "mlrt_multi_render (mlrt_multi.cpp: a context and a stream per device, one RCCL gather) - what a Rust / CLI caller gets")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end sub-record (context creation, first frame, image download, the CLI's window)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (rows gathered through host memory) only to rehearse N>1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -147,6 +267,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.multi == "inproc":
+        if world_size != 1:
+            raise SystemExit("bench.py --multi inproc is ONE process for all --gpus devices: start it without torch.distributed.run")
+        return main_inproc(args, cfg)
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world_size))
     pkg = importlib.import_module("mu-lambda-raytracer_amd")
@@ -238,6 +362,9 @@ def main():
                     "mode": "MLRT_PRECISION_FP32: f32 boxes / rects / shading / primary rays, f64 ray state and sphere quadratic; a mode of the product, "
                             "below the reference's precision (tolerance: per-channel RMSE < 1e-3 against the f64 image)", **f_info}
 
+    e2e = None
+    if rank == 0 and world_size == 1 and not args.no_end_to_end:
+        e2e = end_to_end(pkg, torch, cfg, world, cam, params, head_prec, dev, W, H, spp)
     if rank == 0:
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
@@ -265,6 +392,9 @@ def main():
             out["fast"] = fast
         if cpu:
             out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]  # (vs_baseline stays null: BASELINE.md holds no published number for this metric)
+        if e2e:
+            out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
     world.close()
     if world_size > 1:

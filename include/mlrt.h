@@ -92,14 +92,19 @@ typedef struct mlrt_sphere {  /* shapes.rs:25-42 */
 
 typedef struct mlrt_box {  /* shapes.rs:166-198 Block: six AARects sharing one material.  min <= max componentwise (the
                             * reference's Block::new(p0, p1) with reversed corners yields degenerate sides, aarects.rs:39: rejected).
-                            * Hits carry u = v = 0: a material whose texture chain samples an image (which reads u, v) on a
-                            * box renders texel (0, last row) everywhere. */
+                            * A hit carries the u, v of the face's AARect - its two in-plane axes in axis order, each normalised over
+                            * the face (shapes.rs:172-192, aarects.rs:56-57) - as the reference's does. */
     double min[3], max[3];
     int32_t material;
     int32_t _pad;
 } mlrt_box;
 
-typedef struct mlrt_rect {  /* aarects.rs:19-43 */
+typedef struct mlrt_rect {  /* aarects.rs:19-43.  A rect that is a LEAF OF A BVH (no reference world builds one) is the one place the product
+                             * modes follow the intended geometry and not the reference: AARect::bounding_box (aarects.rs:66-76) sets the
+                             * box's maximum to (a0_v0, a1_v0) - a point in the rect's plane - so the reference's inner node above it
+                             * encloses one corner only and culls most rays that would hit the rect.  MLRT_PRECISION_FP32 / _FP64 bound the
+                             * rect by its true extent (their BVHs are rebuilt from the primitives); MLRT_PRECISION_FP64_STRICT walks the
+                             * caller's bvh_nodes with the caller's bounds and so does whatever those say. */
     int32_t a0, a1;         /* in-plane axes (0=X,1=Y,2=Z); the plane axis is 3-a0-a1 */
     double a0_v0, a0_v1, a1_v0, a1_v1, plane;
     int32_t material;
@@ -199,8 +204,8 @@ typedef struct mlrt_options {
     int32_t tail[8];       /* samples of the tapering passes, counted from the end of a pixel's sample range */
     int32_t stats;         /* debug library only: in-kernel counters */
     int32_t debug_pixel, debug_sample; /* debug library only: print the path of one (pixel, sample); -1 = off */
-    int32_t stall_cap;     /* 0: default.  Kernel-loop iterations a wave may spend without finishing a path before the render
-                            * kernel's watchdog makes it give up (mlrt_context_check) */
+    int32_t stall_cap;     /* debug library only (libmlrt_hip_debug.so; ignored by the release library): kernel-loop iterations a wave may
+                            * spend without finishing a path before the countdown watchdog makes it give up; 0 = default (2^24) */
     int32_t pair_walk;     /* 1 (default): sphere-only scenes are walked through a binary BVH whose nodes hold both children's boxes, nearer
                             * child first, with a per-lane stack in LDS (FP32 and FP64 modes); 0: the threaded list for them too */
 } mlrt_options;
@@ -245,10 +250,12 @@ int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const 
 int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* d_rows,
                                    int32_t n_rows, int32_t* d_rgb_out, double* d_accum_out, void* hip_stream);
 
-/* Waits for the context's last launch and reports its health: the render kernel's persistent waves leave their loop
- * only when every lane is idle, so a kernel-side bug could spin forever; a watchdog in the loop makes a wave that has not
- * finished a single path for ~2^24 iterations give up instead.  MLRT_ERR_HIP + a message naming the lanes' states if that
- * happened (the frame is then incomplete), MLRT_OK otherwise.  mlrt_context_render and mlrt_multi_render call it. */
+/* Waits for the context's last launch and reports its health.  The render kernel's persistent waves leave their loop when every
+ * lane is idle; the release kernels also leave it - and record their lanes' states - in the one state from which nothing can change
+ * any more (no lane traversing, parked for a batch or shading, but some lane still waiting for an accumulator bank), instead of
+ * spinning forever.  MLRT_ERR_HIP + a message naming the lanes' states if that happened (the frame is then incomplete), MLRT_OK
+ * otherwise.  The debug library (libmlrt_hip_debug.so) additionally counts iterations since a path of the wave last ended and gives
+ * up after mlrt_options.stall_cap of them.  mlrt_context_render and mlrt_multi_render call this function. */
 int32_t mlrt_context_check(mlrt_context* ctx);
 
 /* Time of the most recent render kernel of this context in milliseconds, measured with HIP events on the

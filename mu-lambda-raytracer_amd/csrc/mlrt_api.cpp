@@ -757,6 +757,10 @@ struct mlrt_context {
     int32_t block_threads = 0, blocks_per_cu = 1, last_grid = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // mlrt_context_render's device-side row list and frame, kept between calls (a movie renders one frame per call)
+    int32_t* d_host_rows = nullptr;
+    int32_t* d_host_rgb = nullptr;
+    size_t host_rows_cap = 0, host_rgb_cap = 0;
 };
 
 namespace {
@@ -772,6 +776,8 @@ void destroy(mlrt_context* c) {
     if (c->d_cand) (void)hipFree(c->d_cand);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_acc) (void)hipFree(c->d_acc);
+    if (c->d_host_rows) (void)hipFree(c->d_host_rows);
+    if (c->d_host_rgb) (void)hipFree(c->d_host_rgb);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -966,18 +972,24 @@ void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const
     c->timed = true;
 }
 
+// Runs an entry point's body: no exception crosses the ABI, and the caller's current HIP device is what it was on every way out (the
+// body switches to the context's device; an embedding application or a torch process does not expect another device left current).
 template <typename F>
 int32_t guarded(F&& f) {
+    int saved = -1;
+    if (hipGetDevice(&saved) != hipSuccess) { saved = -1; (void)hipGetLastError(); }
+    int32_t rc = MLRT_OK;
     try {
         f();
-        return MLRT_OK;
     } catch (const Fail& e) {
         mlrt::set_last_error(e.msg);
-        return e.code;
+        rc = e.code;
     } catch (const std::exception& e) {
         mlrt::set_last_error(std::string("internal error: ") + e.what());
-        return MLRT_ERR_INVALID;
+        rc = MLRT_ERR_INVALID;
     }
+    if (saved >= 0) (void)hipSetDevice(saved);
+    return rc;
 }
 
 }  // namespace
@@ -1219,7 +1231,9 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
     return rc;
 }
 
-void mlrt_context_destroy(mlrt_context* ctx) { destroy(ctx); }
+void mlrt_context_destroy(mlrt_context* ctx) {
+    (void)guarded([&] { destroy(ctx); });  // (guarded: leaves the caller's current device as it was)
+}
 
 int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* d_rows, int32_t n_rows,
                                    int32_t* d_rgb_out, double* d_accum_out, void* hip_stream) {
@@ -1233,9 +1247,7 @@ int32_t mlrt_context_render_device(mlrt_context* ctx, const mlrt_camera* camera,
 
 int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const mlrt_params* params, const int32_t* rows, int32_t n_rows,
                             int32_t* rgb_out, mlrt_progress_fn progress, void* user) {
-    int32_t* d_rows = nullptr;
-    int32_t* d_rgb = nullptr;
-    const int32_t rc = guarded([&] {
+    return guarded([&] {
         MLRT_REQUIRE(ctx, "context is NULL");
         MLRT_REQUIRE(camera && params, "camera/params is NULL");
         if (!rows) n_rows = params->image_height;
@@ -1249,8 +1261,21 @@ int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const 
             MLRT_REQUIRE(host_rows[(size_t)k] >= 0 && host_rows[(size_t)k] < params->image_height, "row index out of range");
         }
         const size_t row_elems = (size_t)params->image_width * 3;
-        MLRT_HIP(hipMalloc(&d_rows, (size_t)n_rows * sizeof(int32_t)));
-        MLRT_HIP(hipMalloc(&d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t)));
+        // the row list and the frame on the device: the context's own buffers, grown on demand (not allocated and freed per call)
+        if ((size_t)n_rows > ctx->host_rows_cap) {
+            if (ctx->d_host_rows) MLRT_HIP(hipFree(ctx->d_host_rows));
+            ctx->d_host_rows = nullptr; ctx->host_rows_cap = 0;
+            MLRT_HIP(hipMalloc(&ctx->d_host_rows, (size_t)n_rows * sizeof(int32_t)));
+            ctx->host_rows_cap = (size_t)n_rows;
+        }
+        if ((size_t)n_rows * row_elems > ctx->host_rgb_cap) {
+            if (ctx->d_host_rgb) MLRT_HIP(hipFree(ctx->d_host_rgb));
+            ctx->d_host_rgb = nullptr; ctx->host_rgb_cap = 0;
+            MLRT_HIP(hipMalloc(&ctx->d_host_rgb, (size_t)n_rows * row_elems * sizeof(int32_t)));
+            ctx->host_rgb_cap = (size_t)n_rows * row_elems;
+        }
+        int32_t* const d_rows = ctx->d_host_rows;
+        int32_t* const d_rgb = ctx->d_host_rgb;
         MLRT_HIP(hipMemcpy(d_rows, host_rows.data(), (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
         // with a progress callback the image is rendered in a few bands so the caller sees rows complete (each band is a
         // synchronised launch with its own queue tail: four cost ~3 % of a C2 frame, sixteen cost ~15 %); without one: one launch
@@ -1260,16 +1285,17 @@ int32_t mlrt_context_render(mlrt_context* ctx, const mlrt_camera* camera, const 
             const int32_t begin = (int32_t)((int64_t)n_rows * b / bands), end = (int32_t)((int64_t)n_rows * (b + 1) / bands);
             if (end == begin) continue;
             launch(ctx, camera, params, d_rows + begin, end - begin, d_rgb + (size_t)begin * row_elems, nullptr, nullptr);
-            MLRT_HIP(hipStreamSynchronize(nullptr));
-            done = end;
-            if (progress) progress(done, n_rows, user);
+            // a band's rows go home as soon as the band is done (in stream order behind its kernels)
+            MLRT_HIP(hipMemcpyAsync(rgb_out + (size_t)begin * row_elems, d_rgb + (size_t)begin * row_elems, (size_t)(end - begin) * row_elems * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+            if (progress) {
+                MLRT_HIP(hipStreamSynchronize(nullptr));
+                done = end;
+                progress(done, n_rows, user);
+            }
         }
-        MLRT_HIP(hipMemcpy(rgb_out, d_rgb, (size_t)n_rows * row_elems * sizeof(int32_t), hipMemcpyDeviceToHost));
+        MLRT_HIP(hipStreamSynchronize(nullptr));
         if (mlrt_context_check(ctx) != MLRT_OK) throw Fail{MLRT_ERR_HIP, std::string(mlrt_last_error())};
     });
-    if (d_rows) (void)hipFree(d_rows);
-    if (d_rgb) (void)hipFree(d_rgb);
-    return rc;
 }
 
 int32_t mlrt_context_check(mlrt_context* ctx) {

@@ -77,6 +77,39 @@ Rccl& rccl() {
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     return r;
 }
+// The caller's current device, restored on every way out of an entry point: the calls below switch devices as they go, and
+// an embedding application (or a torch process) does not expect libmlrt_hip to leave another device current.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+// The frame's plan, pure host arithmetic (CPU-tested through mlrt_debug_multi_plan): which gather the device list gets, the rows of
+// every device (mlrt_rows_for_device: round-robin), the stride of a device's slice of the root's gather area - device 0 holds the most
+// rows - and so the offset k * stride a peer's rows are received at.
+struct MultiPlan {
+    int32_t gather = MLRT_GATHER_COPY;
+    size_t stride = 0;
+    std::vector<int32_t> n_rows;
+};
+void check_device_list(const int32_t* devices, int32_t n_devices, int32_t gather_mode, int32_t& gather_out) {
+    MULTI_REQUIRE(devices, "devices is NULL");
+    MULTI_REQUIRE(n_devices >= 1 && n_devices <= 64, "n_devices out of range");
+    MULTI_REQUIRE(gather_mode == MLRT_GATHER_AUTO || gather_mode == MLRT_GATHER_RCCL || gather_mode == MLRT_GATHER_COPY, "unknown gather mode");
+    for (int k = 0; k < n_devices; k++) MULTI_REQUIRE(devices[k] >= 0, "negative device ordinal");
+    const bool distinct = std::set<int32_t>(devices, devices + n_devices).size() == (size_t)n_devices;
+    MULTI_REQUIRE(gather_mode != MLRT_GATHER_RCCL || distinct, "MLRT_GATHER_RCCL needs distinct devices (an RCCL communicator has one rank per GPU)");
+    gather_out = gather_mode == MLRT_GATHER_AUTO ? ((distinct && n_devices > 1) ? MLRT_GATHER_RCCL : MLRT_GATHER_COPY) : gather_mode;
+}
+void plan_frame(int32_t n_devices, int32_t width, int32_t height, MultiPlan& P) {
+    MULTI_REQUIRE(width >= 2 && height >= 2, "image must be at least 2x2");
+    const size_t row_elems = (size_t)width * 3;
+    P.n_rows.assign((size_t)n_devices, 0);
+    for (int k = 0; k < n_devices; k++) P.n_rows[(size_t)k] = mlrt_rows_for_device(height, k, n_devices, nullptr);
+    P.stride = (size_t)P.n_rows[0] * row_elems;  // device 0 has the most rows
+}
+
 #define MULTI_RCCL(call) \
     do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) throw Fail{MLRT_ERR_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)}; } while (0)
 
@@ -106,7 +139,8 @@ void release_frame_buffers(mlrt_multi* m) {
         (void)hipSetDevice(m->devices[(size_t)k]);
         if (m->d_rows[(size_t)k]) (void)hipFree(m->d_rows[(size_t)k]);
         if (m->d_rgb[(size_t)k]) (void)hipFree(m->d_rgb[(size_t)k]);
-        if (k > 0 && m->d_bytes[(size_t)k]) (void)hipFree(m->d_bytes[(size_t)k]);
+        // (device 0's byte buffer is a slice of d_gathered unless an RCCL self-transfer was forced: then it is an allocation of its own)
+        if (m->d_bytes[(size_t)k] && m->d_bytes[(size_t)k] != m->d_gathered) (void)hipFree(m->d_bytes[(size_t)k]);
         m->d_rows[(size_t)k] = nullptr; m->d_rgb[(size_t)k] = nullptr; m->d_bytes[(size_t)k] = nullptr;
     }
     (void)hipSetDevice(m->devices[0]);
@@ -134,14 +168,16 @@ void size_for(mlrt_multi* m, int32_t width, int32_t height) {
     if (m->width == width && m->height == height) return;
     release_frame_buffers(m);
     const size_t row_elems = (size_t)width * 3;
-    const int32_t max_rows = mlrt_rows_for_device(height, 0, m->n, nullptr);  // device 0 has the most rows
-    m->stride = (size_t)max_rows * row_elems;
+    MultiPlan plan;
+    plan_frame(m->n, width, height, plan);
+    m->stride = plan.stride;
     MULTI_HIP(hipSetDevice(m->devices[0]));
     MULTI_HIP(hipMalloc(&m->d_gathered, (size_t)m->n * m->stride));
     MULTI_HIP(hipMalloc(&m->d_frame, (size_t)height * row_elems * sizeof(int32_t)));
     for (int k = 0; k < m->n; k++) {
         std::vector<int32_t> rows((size_t)height);
         const int32_t count = mlrt_rows_for_device(height, k, m->n, rows.data());
+        MULTI_REQUIRE(count == plan.n_rows[(size_t)k], "internal error: row plan");
         m->n_rows[(size_t)k] = count;
         if (count == 0) continue;
         MULTI_HIP(hipSetDevice(m->devices[(size_t)k]));
@@ -187,19 +223,18 @@ int32_t mlrt_rows_for_device(int32_t image_height, int32_t k, int32_t n_devices,
 int32_t mlrt_multi_create(const mlrt_scene* scene, const int32_t* devices, int32_t n_devices, int32_t precision, const mlrt_options* options,
                           int32_t gather_mode, mlrt_multi** out) {
     mlrt_multi* m = nullptr;
+    DeviceGuard guard;
     const int32_t rc = guarded([&] {
         MULTI_REQUIRE(scene && devices && out, "scene/devices/out is NULL");
-        MULTI_REQUIRE(n_devices >= 1 && n_devices <= 64, "n_devices out of range");
-        MULTI_REQUIRE(gather_mode == MLRT_GATHER_AUTO || gather_mode == MLRT_GATHER_RCCL || gather_mode == MLRT_GATHER_COPY, "unknown gather mode");
         *out = nullptr;
-        const bool distinct = std::set<int32_t>(devices, devices + n_devices).size() == (size_t)n_devices;
-        MULTI_REQUIRE(gather_mode != MLRT_GATHER_RCCL || distinct, "MLRT_GATHER_RCCL needs distinct devices (an RCCL communicator has one rank per GPU)");
+        int32_t gather = MLRT_GATHER_COPY;
+        check_device_list(devices, n_devices, gather_mode, gather);
         mlrt_options opts;
         if (options) opts = *options; else mlrt_options_from_env(&opts);
         m = new mlrt_multi();
         m->n = n_devices; m->precision = precision;
         m->devices.assign(devices, devices + n_devices);
-        m->gather = gather_mode == MLRT_GATHER_AUTO ? ((distinct && n_devices > 1) ? MLRT_GATHER_RCCL : MLRT_GATHER_COPY) : gather_mode;
+        m->gather = gather;
         m->ctx.assign((size_t)n_devices, nullptr); m->streams.assign((size_t)n_devices, nullptr); m->done.assign((size_t)n_devices, nullptr);
         m->d_rows.assign((size_t)n_devices, nullptr); m->d_rgb.assign((size_t)n_devices, nullptr); m->d_bytes.assign((size_t)n_devices, nullptr);
         m->n_rows.assign((size_t)n_devices, 0);
@@ -232,9 +267,28 @@ int32_t mlrt_multi_create(const mlrt_scene* scene, const int32_t* devices, int32
     return rc;
 }
 
-void mlrt_multi_destroy(mlrt_multi* m) { destroy(m); }
+void mlrt_multi_destroy(mlrt_multi* m) {
+    DeviceGuard guard;
+    destroy(m);
+}
+
+// Test hook (not part of include/mlrt.h): the plan mlrt_multi_create + mlrt_multi_render follow for a device list and a frame, with no
+// device call - argument checks, the gather chosen, rows per device, the stride of the gather area.  out = gather, stride in bytes,
+// then n_devices row counts, then n_devices receive offsets in bytes (k * stride).  Returns what mlrt_multi_create would for the arguments.
+int32_t mlrt_debug_multi_plan(const int32_t* devices, int32_t n_devices, int32_t gather_mode, int32_t width, int32_t height, int64_t* out) {
+    return guarded([&] {
+        MULTI_REQUIRE(out, "out is NULL");
+        int32_t gather = MLRT_GATHER_COPY;
+        check_device_list(devices, n_devices, gather_mode, gather);
+        MultiPlan plan;
+        plan_frame(n_devices, width, height, plan);
+        out[0] = gather; out[1] = (int64_t)plan.stride;
+        for (int k = 0; k < n_devices; k++) { out[2 + k] = plan.n_rows[(size_t)k]; out[2 + n_devices + k] = (int64_t)((size_t)k * plan.stride); }
+    });
+}
 
 int32_t mlrt_multi_render(mlrt_multi* m, const mlrt_camera* camera, const mlrt_params* params, int32_t* rgb_out, mlrt_progress_fn progress, void* user) {
+    DeviceGuard guard;
     return guarded([&] {
         MULTI_REQUIRE(m && camera && params && rgb_out, "multi/camera/params/rgb_out is NULL");
         MULTI_REQUIRE(params->image_width >= 2 && params->image_height >= 2, "image must be at least 2x2");

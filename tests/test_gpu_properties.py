@@ -340,6 +340,56 @@ def test_multi_device_frame_equals_the_single_context_frame(mlrt, earthmap, name
     w.close()
 
 
+def test_distinct_devices_gather_over_rccl(mlrt):
+    """The RCCL branch of mlrt_multi_render with MORE THAN ONE communicator rank - ncclCommInitAll over distinct devices, a grouped
+    ncclSend per peer / ncclRecv per peer on the root at offsets k * stride, the peers' streams ordered against the root's assemble
+    kernel - needs at least two GPUs: skipped on a one-GPU box, run by the first multi-GPU lease.  Heights that the device count
+    does not divide, so the devices hold unequal row counts; the caller's current device must come back unchanged."""
+    import torch
+    n_dev = mlrt.device_count()
+    if n_dev < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d): the RCCL gather with distinct devices is unverified on hardware until it does" % n_dev)
+    w = mlrt.World("random", 42)
+    for width, height in ((150, 101), (96, 67)):
+        cam = mlrt.default_camera(w, width / height)
+        params = mlrt.make_params(w, width, height, 16)
+        for precision in (mlrt.PRECISION_FP64, mlrt.PRECISION_FP32):
+            r = mlrt.Renderer(w, cam, params, precision=precision)
+            single = r.render()
+            r.close()
+            for devices in ([0, 1], list(range(n_dev)), list(range(n_dev))[::-1]):
+                for gather in (mlrt.GATHER_RCCL, mlrt.GATHER_AUTO, mlrt.GATHER_COPY):
+                    before = torch.cuda.current_device()
+                    m = mlrt.MultiRenderer(w, cam, params, devices, precision=precision, gather=gather)
+                    frame, again = m.render(), m.render()
+                    info = m.info()
+                    m.close()
+                    assert torch.cuda.current_device() == before
+                    assert np.array_equal(frame, single) and np.array_equal(again, single), (devices, gather, width, height)
+                    assert info["gather"] == (mlrt.GATHER_COPY if gather == mlrt.GATHER_COPY else mlrt.GATHER_RCCL)
+    w.close()
+
+
+def test_entry_points_leave_the_current_device_alone(mlrt):
+    """mlrt_context_* and mlrt_multi_* switch to their context's device while they work and put the caller's back (an embedding
+    application or a torch process does not expect another device left current).  With one GPU there is only device 0 to come back
+    to: the check is that nothing fails on the way; the multi-GPU test above checks the ordinal itself."""
+    import torch
+    w = mlrt.World("simple", 42)
+    cam = mlrt.default_camera(w, 1.5)
+    params = mlrt.make_params(w, 60, 40, 4)
+    before = torch.cuda.current_device()
+    r = mlrt.Renderer(w, cam, params, precision=mlrt.PRECISION_FP64, device=mlrt.device_count() - 1)
+    img = r.render()
+    r.check()
+    r.close()
+    m = mlrt.MultiRenderer(w, cam, params, [mlrt.device_count() - 1, 0], precision=mlrt.PRECISION_FP64, gather=mlrt.GATHER_COPY)
+    assert np.array_equal(m.render(), img)
+    m.close()
+    assert torch.cuda.current_device() == before
+    w.close()
+
+
 def test_kernel_watchdog_ends_a_stalled_launch_with_an_error(mlrt):
     """The persistent waves leave the kernel loop only when every lane is idle.  Every build gives up when no lane can make
     progress any more; the debug build (build.py --debug) additionally counts iterations since a path of the wave last ended

@@ -1,5 +1,5 @@
 # All BASELINE.json configs that fit one GPU at full size: kernel time and Msamples/s
-python tests/gpu_perf.py c2 c3 2>&1 | grep -v amdgpu | cut -c1-140
+python tools/gpu_perf.py c2 c3 2>&1 | grep -v amdgpu | cut -c1-140
 python - <<'PY'
 import importlib, sys, os, numpy as np
 sys.path.insert(0, os.getcwd())

@@ -1,5 +1,5 @@
 """Exploration helper (not a test): prints GPU-vs-oracle parity metrics and timings for a set of configurations.
-Run on the GPU box:  python tests/gpu_explore.py [quick]"""
+Run on the GPU box:  python tools/gpu_explore.py [quick]"""
 import importlib
 import os
 import sys

@@ -1,7 +1,7 @@
 """Bug hunt (not a test): the randomised parity checks of tests/test_gpu_fuzz.py over many more seeds.  Prints every disagreement.
-usage: python tests/gpu_fuzz_long.py [first_seed] [n_seeds]"""
+usage: python tools/gpu_fuzz_long.py [first_seed] [n_seeds]"""
 import os, sys, time
-HERE = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+HERE = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests")); sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np, torch  # noqa: F401
 import test_gpu_fuzz as fz, directed_cases as dc, oracle_binding as ob, test_gpu_directed as td
 import importlib

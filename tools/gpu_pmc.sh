@@ -2,7 +2,7 @@
 # rocprofv3 --pmc passes (each its own run, counters only) on ONE launch of a bench workload, summarised into
 # gpurun_out/<tag>_pmc_<config>_<dtype>.{json,txt} (copy the ones to be judged into profiles/).
 export TMPDIR=/tmp
-CFG=${1:-c2}; PREC=${2:-fp64}; TAG=${3:-r02}
+CFG=${1:-c2}; PREC=${2:-fp64}; TAG=${3:-r03}
 DT=f64; [ "$PREC" = fp32 ] && DT=f32
 ROOT=$GRAFT_REPO_ROOT
 O=$ROOT/gpurun_out/${TAG}_pmcraw_${CFG}_${DT}

@@ -13,6 +13,6 @@ bash tools/gpu_pmc.sh c2 fp32 $R > gpurun_out/${R}_pmc_c2_f32.log 2>&1
 bash tools/gpu_pmc.sh c4 fp32 $R > gpurun_out/${R}_pmc_c4_f32.log 2>&1
 bash tools/gpu_pmc.sh c4 fp64 $R > gpurun_out/${R}_pmc_c4_f64.log 2>&1
 tools/microbench/bin/valu_issue > gpurun_out/${R}_valu_issue.txt 2>&1
-python3 tests/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > gpurun_out/${R}_strong_scaling_probe.txt
-MLRT_PREC=1 python3 tests/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu >> gpurun_out/${R}_strong_scaling_probe.txt
+python3 tools/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > gpurun_out/${R}_strong_scaling_probe.txt
+MLRT_PREC=1 python3 tools/gpu_scale_probe.py 1 2 4 8 2>&1 | grep -v amdgpu >> gpurun_out/${R}_strong_scaling_probe.txt
 ls gpurun_out/${R}_trace gpurun_out/${R}_trace_c4

@@ -29,7 +29,9 @@ def main():
             (render if "mlrt_render_kernel" in k else other)[r["Counter_Name"]] += float(r["Counter_Value"])
     g = lambda n: render.get(n, 0.0)
     cycles = g("GRBM_GUI_ACTIVE") / 8.0  # summed over the 8 XCDs
-    out = {"config": config, "dtype": dtype, "samples_per_launch": samples, "kernels": sorted(names),
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from build_stamp import stamp
+    out = {"config": config, "dtype": dtype, "samples_per_launch": samples, "build_stamp": stamp(), "kernels": sorted(names),
            "counters_render_kernel": dict(sorted(render.items())), "counters_prepass_and_resolve": dict(sorted(other.items()))}
     if g("SQ_INSTS_VALU"):
         out["valu_insts_per_sample"] = g("SQ_INSTS_VALU") / samples
@@ -41,6 +43,8 @@ def main():
         out["valu_issue_frac"] = g("SQ_INSTS_VALU") * 2.0 / (SIMDS * cycles)  # 1 wave-instruction / 2 cycles / SIMD-32
     if g("SQ_ACTIVE_INST_VALU"):
         out["lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0)
+        # lane-level instructions (an instruction counts once per ACTIVE lane): what fewer instructions, not emptier waves, brings down
+        out["valu_lane_insts_per_sample"] = out.get("valu_insts_per_sample", 0.0) * 64.0 * out["lane_utilisation"]
         out["valu_active_quads_per_inst"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU")
     if g("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_share"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
@@ -59,10 +63,11 @@ def main():
     json.dump(out, open(prefix + ".json", "w"), indent=1)
     with open(prefix + ".txt", "w") as f:
         f.write("# rocprofv3 --pmc passes on ONE launch of %s (%s), render kernel only unless noted; tools/gpu_pmc.sh + tools/pmc_summary.py\n" % (config, dtype))
+        f.write("# build: lib sha256 %s, sources sha256 %s\n" % (out["build_stamp"]["lib_sha256"], out["build_stamp"]["source_sha256"]))
         for k, v in sorted(render.items()):
             f.write("%-32s %.6g\n" % (k, v))
         for k in ("gpu_cycles", "valu_issue_frac", "lane_utilisation", "lds_bank_conflict_share", "valu_insts_per_sample", "salu_insts_per_sample", "lds_insts_per_sample",
-                  "valu_active_quads_per_inst", "hbm_bytes_per_launch"):
+                  "valu_active_quads_per_inst", "valu_lane_insts_per_sample", "hbm_bytes_per_launch"):
             if k in out:
                 f.write("%-32s %.6g\n" % (k, out[k]))
         if "wave_cycle_split" in out:
