@@ -1673,6 +1673,8 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_trav = __ballot(phase == PH_TRAV);
         // (B) batched special entries
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
+        // (measured and not kept: the batches also run as soon as fewer than 8 / 16 / 24 / 32 lanes still traverse - C2 f64 +1 / +1.5 / +2.3 / +4 %,
+        // final_scene f64 +0.6 / +4.7 / +8.5 / +12 %: a batch that runs early runs with fewer lanes, and it is the batches that cost)
         if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= (FEAT == 0 ? MLRT_T_SPECIAL_LEAN : MLRT_T_SPECIAL) || m_trav == 0ull))) {
             if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
             if constexpr (PAIR) {
