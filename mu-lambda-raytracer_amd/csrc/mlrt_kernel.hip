@@ -1508,7 +1508,8 @@ void mlrt_render_kernel(const KParams<real> P) {
     // the instructions it issues, not by the pop's round trip.  Only traversing lanes fetching their next node: +0.5 %.  Two rounds of
     // the sphere batch for lanes whose pop is another leaf: +2 %.  Metal / Dielectric hits - a fifth of `random`'s hits, a third of a
     // shading batch's code - shaded in batches of their own once 8 / 16 / 24 such lanes wait: +8 / +10 / +14 %: a lane that waits costs
-    // more than the code its absence lets a batch skip.)
+    // more than the code its absence lets a batch skip.  The two children's plane distances as six v_pk_fma_f32 (boxes interleaved in the
+    // node): +4 % in both builds - the pairs of ray constants cost registers (16 B of scratch appear) and copies.)
     int16_t* const stack_lane = reinterpret_cast<int16_t*>(acc_base + (BLOCK / 64) * kAccBytes + kFrameParamBytes) + threadIdx.x;
     int sp = BLOCK, top = kPairEnd;
 

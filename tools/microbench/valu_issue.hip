@@ -84,6 +84,29 @@ __global__ __launch_bounds__(1024) void k_mad_u64_u32(double* out, unsigned long
     out[blockIdx.x * blockDim.x + threadIdx.x] = (double)s;
     if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
+// The same v_fma_f32 stream with part of the wave switched off (EXEC set by the branch around the loop): which lane groups cost issue cycles?
+// MASK: lanes for which (lane & AND) == EQ run the loop.
+#define DEFINE_KERNEL_MASKED(NAME, AND, EQ)                                                                  \
+    __global__ __launch_bounds__(1024) void NAME(float* out, unsigned long long* cycles, float b, float c) { \
+        float a[kUnroll];                                                                                    \
+        for (int k = 0; k < kUnroll; k++) a[k] = (float)(threadIdx.x + k) * 1e-3f + 1.0f;                    \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                          \
+        if (((threadIdx.x & 63) & (AND)) == (EQ)) {                                                          \
+            for (int it = 0; it < kIters; it++) {                                                            \
+                _Pragma("unroll") for (int k = 0; k < kUnroll; k++) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(a[k]) : "s"(b), "s"(c) : "vcc"); \
+            }                                                                                                \
+        }                                                                                                    \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                          \
+        float s = 0; for (int k = 0; k < kUnroll; k++) s += a[k];                                            \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                      \
+        if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;        \
+    }
+DEFINE_KERNEL_MASKED(k_fma_low32, 32, 0)    // lanes 0-31
+DEFINE_KERNEL_MASKED(k_fma_high32, 32, 32)  // lanes 32-63
+DEFINE_KERNEL_MASKED(k_fma_low16, 48, 0)    // lanes 0-15
+DEFINE_KERNEL_MASKED(k_fma_even, 1, 0)      // every other lane
+DEFINE_KERNEL_MASKED(k_fma_q0q2, 16, 0)     // lanes 0-15 and 32-47
+DEFINE_KERNEL_MASKED(k_fma_lane0, 63, 0)    // one lane
 DEFINE_KERNEL_F64(k_cmp_f64, "v_cmp_lt_f64 vcc, %0, %1")
 DEFINE_KERNEL_F64(k_div_fixup_f64, "v_div_fixup_f64 %0, %0, %1, 1.0")
 DEFINE_KERNEL_F64(k_mov_b64, "v_mov_b64 %0, %1")
@@ -144,6 +167,7 @@ int main(int argc, char** argv) {
         RUN32(k_fma_f32); RUN32(k_mul_f32); RUN32(k_add_f32); RUN32(k_max_f32); RUN32(k_rcp_f32); RUN32(k_sqrt_f32); RUN32(k_sin_f32); RUN32(k_mul_lo_u32); RUN32(k_xor_b32);
         RUN64(k_fma_f64); RUN64(k_add_f64); RUN64(k_mul_f64); RUN64(k_max_f64); RUN64(k_min_f64); RUN64(k_rcp_f64); RUN64(k_sqrt_f64); RUN64(k_rsq_f64);
         RUN64(k_mad_u64_u32); RUN64(k_cmp_f64); RUN64(k_div_fixup_f64); RUN64(k_mov_b64);
+        RUN32(k_fma_low32); RUN32(k_fma_high32); RUN32(k_fma_low16); RUN32(k_fma_even); RUN32(k_fma_q0q2); RUN32(k_fma_lane0);
     }
     return 0;
 }
