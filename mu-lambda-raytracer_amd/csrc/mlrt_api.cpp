@@ -761,6 +761,7 @@ struct mlrt_context {
     int32_t* d_host_rows = nullptr;
     int32_t* d_host_rgb = nullptr;
     size_t host_rows_cap = 0, host_rgb_cap = 0;
+    const double* d_ray_table = nullptr;  // set for the duration of a ray frame (mlrt_debug_ray_frame)
 };
 
 namespace {
@@ -852,7 +853,7 @@ void plan_tiles(int width, int n_rows, int spp, double waves, bool lean, const m
 // stays small against the frame, and max_depth small enough for the list cursor the kernel keeps in the upper bits of a
 // lane's depth word (max_depth is any i32 in the reference: above 65535 the lanes simply walk the BVH).
 bool primary_lists_wanted(const mlrt_context* c, const mlrt_params* p) {
-    return (c->variant == 1 || c->variant == 2) && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && (c->pair_walk ? c->n_prims : c->n_nodes) <= 4096 &&
+    return (c->variant == 1 || c->variant == 2) && !c->d_ray_table && c->precision != MLRT_PRECISION_FP64_STRICT && c->opt.primary_lists != 0 && (c->pair_walk ? c->n_prims : c->n_nodes) <= 4096 &&
            p->image_height < 65536 && p->max_depth <= 0xFFFF;
 }
 
@@ -873,7 +874,8 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
         K.bg_top[k] = (R)p->background_top[k]; K.bg_bottom[k] = (R)p->background_bottom[k];
     }
     K.lens_radius = cam->lens_radius;
-    K.has_lens = cam->lens_radius != 0.0 ? 1 : 0;
+    K.has_lens = (cam->lens_radius != 0.0 ? 1 : 0) | (c->d_ray_table ? 2 : 0);
+    K.ray_table = c->d_ray_table;
     K.inv_wm1 = 1.0 / ((double)p->image_width - 1.0); K.inv_hm1 = 1.0 / ((double)p->image_height - 1.0);
     K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
@@ -1336,6 +1338,47 @@ int32_t mlrt_context_info(mlrt_context* ctx, int64_t out[4]) {
 }
 
 int32_t mlrt_context_kernel_variant(mlrt_context* ctx) { return ctx ? ctx->variant : -1; }
+
+// Test hook (not part of include/mlrt.h): a "ray frame" through the RELEASE render kernel - tile queue, lane state machine, batches and
+// all.  Sample s of pixel p of a W x H frame starts on rays[p * spp + s] (origin xyz, direction xyz; p = j * W + i, row 0 = bottom)
+// instead of the camera's ray; everything after the primary ray is the product path (the sample's Philox stream is positioned behind its
+// four camera draws as always).  accum_out [H][W][3]: the f64 colour sums of the pixels; rgb_out [H][W][3] or NULL.  The primary
+// candidate lists, which are derived from the camera, are off for the frame.  tests/test_gpu_ray_frames.py compares with the oracle's
+// trace of the same rays.
+int32_t mlrt_debug_ray_frame(mlrt_context* ctx, const mlrt_params* params, const double* rays, double* accum_out, int32_t* rgb_out) {
+    double* d_table = nullptr;
+    double* d_accum = nullptr;
+    int32_t* d_rgb = nullptr;
+    const int32_t rc = guarded([&] {
+        MLRT_REQUIRE(ctx && params && rays && accum_out, "NULL argument");
+        mlrt_camera cam{};  // unused by a ray frame, but checked like any camera
+        cam.origin[2] = 1.0; cam.lower_left_corner[0] = -1.0; cam.lower_left_corner[1] = -1.0; cam.horizontal[0] = 2.0; cam.vertical[1] = 2.0; cam.u[0] = 1.0; cam.v[1] = 1.0;
+        check_params(&cam, params, params->image_height);
+        MLRT_HIP(hipSetDevice(ctx->device));
+        const size_t pixels = (size_t)params->image_width * (size_t)params->image_height;
+        const size_t n_rays = pixels * (size_t)params->samples_per_pixel;
+        MLRT_HIP(hipMalloc(&d_table, n_rays * 6 * sizeof(double)));
+        MLRT_HIP(hipMemcpy(d_table, rays, n_rays * 6 * sizeof(double), hipMemcpyHostToDevice));
+        MLRT_HIP(hipMalloc(&d_accum, pixels * 3 * sizeof(double)));
+        MLRT_HIP(hipMalloc(&d_rgb, pixels * 3 * sizeof(int32_t)));
+        ctx->d_ray_table = d_table;
+        try {
+            launch(ctx, &cam, params, nullptr, params->image_height, d_rgb, d_accum, nullptr);
+        } catch (...) {
+            ctx->d_ray_table = nullptr;
+            throw;
+        }
+        ctx->d_ray_table = nullptr;
+        MLRT_HIP(hipStreamSynchronize(nullptr));
+        MLRT_HIP(hipMemcpy(accum_out, d_accum, pixels * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (rgb_out) MLRT_HIP(hipMemcpy(rgb_out, d_rgb, pixels * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (mlrt_context_check(ctx) != MLRT_OK) throw Fail{MLRT_ERR_HIP, std::string(mlrt_last_error())};
+    });
+    if (d_table) (void)hipFree(d_table);
+    if (d_accum) (void)hipFree(d_accum);
+    if (d_rgb) (void)hipFree(d_rgb);
+    return rc;
+}
 
 // Debug only (MLRT_STATS=1; not part of the ABI headers): copies and clears the in-kernel counters.
 int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[16]) {

@@ -140,7 +140,7 @@ struct KParams {
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
     double lens_radius;
     double inv_wm1, inv_hm1;  // 1 / (width - 1), 1 / (height - 1)  (cam_origin ... inv_hm1 stay contiguous: the kernel copies them as 21 doubles)
-    int32_t has_lens;    // lens_radius != 0
+    int32_t has_lens;    // bit 0: lens_radius != 0; bit 1: ray_table is set (a ray frame)
     int32_t width, height, spp, max_depth;
     uint32_t seed_lo, seed_hi;
     int32_t bg_kind;
@@ -169,6 +169,10 @@ struct KParams {
     const uint16_t* primary_lists;  // or nullptr; sphere-only scene + pinhole camera: [n_groups][16] per-pixel-group candidate records (mlrt_primary_lists_kernel):
                                     // a group's primary rays test those entries instead of walking the BVH
     int32_t debug_pixel, debug_sample;  // >= 0: printf the path of that (pixel, sample) from the kernel (MLRT_DEBUG_PIXEL=pixel,sample)
+    // Test instrument ("ray frames", mlrt_debug_ray_frame): when not null, sample s of pixel p starts on ray_table[p * spp + s] (origin xyz,
+    // direction xyz) instead of the camera's ray - the sample's Philox block 0 is consumed as always.  Read from the kernel-argument
+    // segment at its one point of use (gen_camera_ray); kept last so that no other field moves.
+    const double* ray_table;
 };
 
 }  // namespace mlrt

@@ -1170,6 +1170,16 @@ DEV V3 background_color(const KParams<real>& P, const FrameParams& F, P3 d) {  /
     return ((real)1 - t) * ld3(F.bg_bottom) + t * ld3(F.bg_top);
 }
 
+// KParams::ray_table read from the kernel-argument segment at its point of use, and only when bit 1 of KParams::has_lens announces a
+// table (a test instrument must not cost the render kernels a scalar register pair, nor a load per regeneration)
+DEV const double* ray_table_pointer() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const double* const volatile*>(args + offsetof(KParams<real>, ray_table));
+#else
+    return nullptr;
+#endif
+}
 // raytrace.rs:191-193 + Camera::get_ray, camera.rs:40-48, in f64 in both builds: the uniforms are 24-bit values
 // exact in either precision, so the primary ray is bit-identical to the oracle's (parity build; the fast build
 // evaluates the lens offset's sin/cos in f32).  A fresh sample's four draws - u, v and the lens sample, drawn by
@@ -1194,7 +1204,7 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
         float dy = F.through0[1] + sf * F.hor_f[1] + tf * F.ver_f[1];
         float dz = F.through0[2] + sf * F.hor_f[2] + tf * F.ver_f[2];
         o = ld3p(F.cam_origin);
-        if (P.has_lens) {
+        if (P.has_lens & 1) {
             const float u1 = ((float)(b2 >> 8) + 1.0f) * (float)(1.0 / 16777216.0);
             const float turn = (float)(b3 >> 8) * (float)(1.0 / 16777216.0);
             const float r = (float)F.lens_radius * __builtin_amdgcn_sqrtf(u1);
@@ -1213,7 +1223,7 @@ DEV void gen_camera_ray(const KParams<real>& P, const FrameParams& F, Rng& g, Rn
     const double t = kFast ? ((double)j + u01d(b1)) * F.inv_hm1 : Divisor((double)P.height - 1.0, F.inv_hm1).one((double)j + u01d(b1));
     const P3 origin = ld3p(F.cam_origin);
     const P3 through = ld3p(F.cam_llc) + s * ld3p(F.cam_horizontal) + t * ld3p(F.cam_vertical) - origin;
-    if (P.has_lens) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is: nothing to add
+    if (P.has_lens & 1) {  // wave-uniform; with a pinhole the offset is exactly zero whatever the lens sample is: nothing to add
         const double u1 = ((double)(b2 >> 8) + 1.0) * (1.0 / 16777216.0);
         double cs, sn;
         if (kFast) { const double turn = u01d(b3); cs = (double)__builtin_amdgcn_cosf((float)turn); sn = (double)__builtin_amdgcn_sinf((float)turn); }
@@ -1331,7 +1341,7 @@ __global__ __launch_bounds__(64) void mlrt_primary_lists_kernel(const KParams<re
     // to the focus plane: the spheres it can hit are within lens_radius * max(1, t / focus_dist) of the pinhole pyramid.
     const P3 fw = mkp(-base.x - 0.5 * hor.x - 0.5 * ver.x, -base.y - 0.5 * hor.y - 0.5 * ver.y, -base.z - 0.5 * hor.z - 0.5 * ver.z);  // focus_dist * w
     const real lens = (real)(P.lens_radius * 1.001);
-    const real inv_focus = P.has_lens ? (real)(1.0 / sqrt(fw.x * fw.x + fw.y * fw.y + fw.z * fw.z)) : (real)0;
+    const real inv_focus = (P.has_lens & 1) ? (real)(1.0 / sqrt(fw.x * fw.x + fw.y * fw.y + fw.z * fw.z)) : (real)0;
     // the four side planes (inward unit normals through the camera origin) of the pyramid over pixels [xa, xb) of row j,
     // footprint in the (s, t) coordinates of Camera::get_ray, 1/100 pixel wider on every side
     struct Pyramid { V3 left, right, bottom, top; };
@@ -1846,6 +1856,10 @@ void mlrt_render_kernel(const KParams<real> P) {
                     g.pixel = (uint32_t)(t_j * P.width + t_x0 + p_in_tile);
                     g.sample = (uint32_t)smp;
                     gen_camera_ray(P, F, g, key, t_x0 + p_in_tile, t_j, o, d);
+                    if (MLRT_RARELY(P.has_lens & 2)) {  // a ray frame (mlrt_debug_ray_frame): the sample's ray comes from the table
+                        const double* q = ray_table_pointer() + ((size_t)g.pixel * (size_t)P.spp + g.sample) * 6;
+                        o = mkp(q[0], q[1], q[2]); d = mkp(q[3], q[4], q[5]);
+                    }
                     thr = mk(1, 1, 1);
                     depth = P.max_depth;
                     has_path = true;

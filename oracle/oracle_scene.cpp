@@ -196,6 +196,23 @@ void orc_scene_probe_rays(void* h, uint64_t seed, int n, const double* rays, con
     }
 }
 
+// RecursiveRayTracer::trace (raytrace.rs:79-107) of GIVEN rays: the radiance of ray i with the device's Philox stream of (pixel, sample) =
+// ps[i] positioned behind a sample's four camera draws (draw index 4: raytrace.rs:191-192 + camera.rs:41).  out[n][3].  The checker of the
+// "ray frames" the release kernel renders (tests/test_gpu_ray_frames.py).
+void orc_scene_trace_rays(void* h, int bg_kind, const double* top, const double* bottom, int max_depth, uint64_t seed, int n, const double* rays,
+                          const uint32_t* ps, double* out) {
+    const SceneWorld& w = *(SceneWorld*)h;
+    Background bg;
+    bg.kind = bg_kind;
+    bg.top = Color(top[0], top[1], top[2]); bg.bottom = Color(bottom[0], bottom[1], bottom[2]);
+    for (int i = 0; i < n; i++) {
+        const Ray ray(Point3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), Vec3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
+        PhiloxStream rng = stream_at(seed, ps[i * 2], ps[i * 2 + 1], 4u);
+        const Color c = trace_internal(ray, w.root, bg, max_depth, rng);
+        for (int k = 0; k < 3; k++) out[i * 3 + k] = c.e[k];
+    }
+}
+
 // Texture::value of texture `tex` at uvp[n][5] = u, v, p xyz
 void orc_scene_texture_value(void* h, int tex, int n, const double* uvp, double* out) {
     const SceneWorld& w = *(SceneWorld*)h;

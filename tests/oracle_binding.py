@@ -116,6 +116,14 @@ class OracleScene:
                                 accum.ctypes.data_as(C.c_void_p) if want_accum else None)
         return rgb, accum
 
+    def trace_rays(self, seed, rays, pixel_sample, max_depth, background=1, top=(0.5, 0.7, 1.0), bottom=(1.0, 1.0, 1.0)):
+        """trace_internal (raytrace.rs:79-102) of given rays, each with the Philox stream of its (pixel, sample) behind the four camera draws."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64); ps = np.ascontiguousarray(pixel_sample, dtype=np.uint32)
+        out = np.zeros((len(rays), 3))
+        self.L.orc_scene_trace_rays(C.c_void_p(self.handle), int(background), (C.c_double * 3)(*top), (C.c_double * 3)(*bottom), int(max_depth), C.c_uint64(seed), len(rays),
+                                    rays.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
     def texture_value(self, tex, uvp):
         uvp = np.ascontiguousarray(uvp, dtype=np.float64)
         out = np.zeros((len(uvp), 3))
