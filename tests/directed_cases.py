@@ -120,7 +120,16 @@ class MiniScene:
             if kind == 1:
                 b = self.boxes[idx]
                 return np.minimum(b["min"], b["max"]).astype(np.float64), np.maximum(b["min"], b["max"]).astype(np.float64)
-            raise ValueError("rects are never put in a BVH (quirk Q2)")
+            # AARect::bounding_box (aarects.rs:66-76) as the reference computes it: BOTH corners at (a0_v0, a1_v0) - a point in the rect's
+            # plane, 0.002 thick - so an inner node above a rect leaf encloses one corner of it only (no reference world does this;
+            # include/mlrt.h mlrt_rect says what the product modes do instead)
+            r = self.rects[idx]
+            ap = 3 - r["a0"] - r["a1"]
+            lo, hi = np.zeros(3), np.zeros(3)
+            lo[r["a0"]] = hi[r["a0"]] = r["a0_v0"]
+            lo[r["a1"]] = hi[r["a1"]] = r["a1_v0"]
+            lo[ap], hi[ap] = r["plane"] - 0.001, r["plane"] + 0.001
+            return lo, hi
 
         def build(lo, hi):
             if hi - lo == 1:

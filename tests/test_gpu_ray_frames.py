@@ -188,3 +188,50 @@ def test_a_nan_sample_contributes_zero_where_the_reference_zeroes_the_pixel(mlrt
         assert np.allclose(accum[0, 0], TOP, atol=1e-9), (build, accum[0, 0])
         assert np.allclose(accum[0, 1], 2 * np.array(TOP), atol=1e-9)
         assert rgb[0, 0].min() > 0
+
+
+def test_a_rect_that_is_a_bvh_leaf(mlrt, oracle):
+    """No reference world puts an AARect into a BHV; if one did, AARect::bounding_box (aarects.rs:66-76) - maximum set to (a0_v0, a1_v0):
+    a point - would make the inner node above it enclose one corner of the rect only, and the reference would cull most rays that hit
+    the rect.  The product modes (FP64, FP32) rebuild their BVHs from the primitives' true extents and render the intended geometry:
+    the same picture as the rect as a plain list member.  The strict build walks the caller's bvh_nodes with the caller's bounds and so
+    agrees with the reference on the scene as given (include/mlrt.h, mlrt_rect).  Pinned here both ways."""
+    m = mlrt
+
+    def scene(in_bvh):
+        sc = dc.MiniScene(m)
+        red, grey = sc.lambertian(sc.solid(0.65, 0.05, 0.05)), sc.lambertian(sc.solid(0.5, 0.5, 0.5))
+        rect = sc.rect(0, 1, -2.0, 2.0, -2.0, 2.0, -5.0, red)
+        ball = sc.sphere((-3.0, -3.0, -5.0), 0.5, grey)  # next to the corner the reference takes for the whole rect
+        far_box = sc.box((20.0, 20.0, -8.0), (21.0, 21.0, -7.0), grey)  # (keeps the scene on the FULL variants)
+        if in_bvh:
+            sc.add_bvh([rect, ball])
+        else:
+            sc.add_prim(rect); sc.add_prim(ball)
+        sc.add_prim(far_box)
+        return sc.to_ctypes()
+
+    rng = np.random.default_rng(5)
+    n = 400
+    target = np.stack([rng.uniform(-1.9, 1.9, n), rng.uniform(-1.9, 1.9, n), np.full(n, -5.0)], axis=1)  # points of the rect
+    origin = np.stack([rng.uniform(-1.0, 1.0, n), rng.uniform(-1.0, 1.0, n), np.full(n, 3.0)], axis=1)
+    rays = np.concatenate([origin, target - origin], axis=1)
+    tree, flat = scene(True), scene(False)
+    osc = OracleScene(oracle, tree)
+    probe = osc.probe_rays(1, rays, np.tile(np.array([[0, 0, 4]], dtype=np.uint32), (n, 1)))
+    osc.close()
+    assert (probe[:, 0] == 0).mean() > 0.5, "the reference culls most of these rays (its inner node encloses a corner of the rect only)"
+    spp, depth = 2, 3
+    got = {}
+    for build in ("fp64", "fp32", "fp64_strict"):
+        ctx = make_context(m, tree, build)
+        got[build], table, ids = ray_frame(m, ctx, rays, spp, depth, 1)
+        m.lib().mlrt_context_destroy(ctx)
+    osc_tree, osc_flat = OracleScene(oracle, tree), OracleScene(oracle, flat)
+    want_tree = osc_tree.trace_rays(1, table, ids, depth, background=1, top=TOP, bottom=BOTTOM).reshape(2, -1, spp, 3).sum(axis=2)
+    want_flat = osc_flat.trace_rays(1, table, ids, depth, background=1, top=TOP, bottom=BOTTOM).reshape(2, -1, spp, 3).sum(axis=2)
+    osc_tree.close(); osc_flat.close()
+    assert np.abs(want_tree - want_flat).max() > 0.1  # (the two readings of the scene do differ)
+    compare("fp64", got["fp64"], want_flat, ["rect in a BVH"] * n, spp)        # product: the intended geometry
+    compare("fp32", got["fp32"], want_flat, ["rect in a BVH"] * n, spp)
+    compare("fp64_strict", got["fp64_strict"], want_tree, ["rect in a BVH"] * n, spp)  # strict: the reference on the scene as given
