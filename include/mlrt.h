@@ -208,6 +208,9 @@ typedef struct mlrt_options {
                             * spend without finishing a path before the countdown watchdog makes it give up; 0 = default (2^24) */
     int32_t pair_walk;     /* 1 (default): sphere-only scenes are walked through a binary BVH whose nodes hold both children's boxes, nearer
                             * child first, with a per-lane stack in LDS (FP32 and FP64 modes); 0: the threaded list for them too */
+    int32_t split_roles;   /* 1: sphere-only scenes on the pair structure are rendered by the split-role kernel - traversal waves and shading
+                            * waves of a workgroup handing paths to each other through two queues in LDS - when its queues fit the LDS next to
+                            * the scene; 0: every wave does everything.  Same image either way. */
 } mlrt_options;
 void mlrt_options_default(mlrt_options* out);
 /* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,

@@ -107,7 +107,7 @@ class Options(C.Structure):
     """mlrt_options (include/mlrt.h): tuning / diagnostic switches, none of which may change an f64 image."""
     _fields_ = [("sah", C.c_int32), ("leaf_wrap", C.c_int32), ("primary_lists", C.c_int32), ("lds_scene", C.c_int32), ("force_full", C.c_int32), ("cull_f64", C.c_int32),
                 ("tile_samples", C.c_int32), ("tile_queues", C.c_int32), ("n_tail", C.c_int32), ("tail", C.c_int32 * 8), ("stats", C.c_int32),
-                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32), ("pair_walk", C.c_int32)]
+                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32), ("pair_walk", C.c_int32), ("split_roles", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)

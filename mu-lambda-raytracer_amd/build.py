@@ -70,7 +70,7 @@ UNITS = [
     ("worlds.o", os.path.join(HERE, "host", "worlds.cpp"), ["-ffp-contract=off"]),
     ("jpeg.o", os.path.join(HERE, "host", "jpeg_baseline.cpp"), ["-ffp-contract=off"]),
 ]
-HEADERS = [os.path.join(ROOT, "include", "mlrt.h"), os.path.join(ROOT, "include", "mlrt_host.h"), os.path.join(HERE, "csrc", "mlrt_device.hpp"),
+HEADERS = [os.path.join(ROOT, "include", "mlrt.h"), os.path.join(ROOT, "include", "mlrt_host.h"), os.path.join(HERE, "csrc", "mlrt_device.hpp"), os.path.join(HERE, "csrc", "mlrt_split.inc"),
            os.path.join(HERE, "host", "host_internal.hpp"), os.path.join(HERE, "host", "pcg64.hpp"), os.path.abspath(__file__)]
 
 

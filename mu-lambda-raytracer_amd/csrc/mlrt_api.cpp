@@ -30,7 +30,8 @@
     int mlrt_occupancy_##sfx(int variant, int lds_scene, size_t dyn_lds);                                                          \
     int mlrt_perlin_in_hbm_##sfx(void);                                                                                           \
     int mlrt_lean_materials_in_hbm_##sfx(void);                                                                                    \
-    int mlrt_has_pair_walk_##sfx(void);
+    int mlrt_has_pair_walk_##sfx(void);                                                                                            \
+    size_t mlrt_split_lds_bytes_##sfx(int stack_levels);
 extern "C" {
 MLRT_DECLARE_BUILD(f32)
 MLRT_DECLARE_BUILD(f64)
@@ -65,13 +66,14 @@ struct KernelBuild {
     int (*lean_materials_in_hbm)(void);
     int (*has_pair_walk)(void);
     int (*variant_count)(void);
+    size_t (*split_lds_bytes)(int);
 };
 #ifdef MLRT_DEBUG_BUILD
 #define MLRT_PROBE_OF(sfx) mlrt_probe_launch_##sfx
 #else
 #define MLRT_PROBE_OF(sfx) nullptr
 #endif
-#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx, mlrt_has_pair_walk_##sfx, mlrt_variant_count_##sfx}
+#define MLRT_BUILD_ROW(sfx) {mlrt_launch_##sfx, mlrt_instrumented_##sfx, mlrt_variant_features_##sfx, mlrt_block_threads_##sfx, mlrt_acc_bytes_per_wave_##sfx, mlrt_lds_frame_bytes_##sfx, mlrt_occupancy_##sfx, MLRT_PROBE_OF(sfx), mlrt_perlin_in_hbm_##sfx, mlrt_lean_materials_in_hbm_##sfx, mlrt_has_pair_walk_##sfx, mlrt_variant_count_##sfx, mlrt_split_lds_bytes_##sfx}
 const KernelBuild kBuilds[4] = {MLRT_BUILD_ROW(f32), MLRT_BUILD_ROW(f64), MLRT_BUILD_ROW(f64s), MLRT_BUILD_ROW(f64c)};  // MLRT_PRECISION_*; [3]: FP64 with options.cull_f64
 
 struct Fail {
@@ -740,6 +742,7 @@ struct mlrt_context {
     int32_t off[6] = {0, 0, 0, 0, 0, 0};
     int32_t n_nodes = 0, n_sphere_index = 0;
     bool pair_walk = false;  // the blob is the pair structure (mlrt_device.hpp DPair), variant == 2
+    bool split_roles = false;  // ... rendered by the split-role kernel (mlrt_split.inc)
     int32_t off_prims = 0, off_prim_mat = 0, n_prims = 0, stack_levels = 0;
     std::vector<unsigned char*> d_image_pixels;
     DImage* d_images = nullptr;
@@ -865,7 +868,7 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
     K.off_perlin_vec = c->off[3]; K.off_perlin_perm = c->off[4];
     K.off_sphere_index = c->off[5]; K.n_sphere_index = c->n_sphere_index;
     K.n_nodes = c->n_nodes;
-    K.pair_walk = c->pair_walk ? 1 : 0; K.off_prims = c->off_prims; K.off_prim_mat = c->off_prim_mat; K.n_prims = c->n_prims; K.stack_levels = c->stack_levels;
+    K.pair_walk = c->pair_walk ? (c->split_roles ? 2 : 1) : 0; K.off_prims = c->off_prims; K.off_prim_mat = c->off_prim_mat; K.n_prims = c->n_prims; K.stack_levels = c->stack_levels;
     K.images = c->d_images;
     for (int k = 0; k < 3; k++) {
         K.cam_origin[k] = cam->origin[k]; K.cam_llc[k] = cam->lower_left_corner[k];
@@ -1051,7 +1054,7 @@ int32_t mlrt_device_count(void) {
 void mlrt_options_default(mlrt_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);
-    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0; o->pair_walk = 1;
+    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0; o->pair_walk = 1; o->split_roles = 0;
     o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
     o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0; o->stall_cap = 0;
 }
@@ -1066,6 +1069,7 @@ void mlrt_options_from_env(mlrt_options* o) {
     if (std::getenv("MLRT_FORCE_FULL")) o->force_full = 1;
     if (std::getenv("MLRT_CULL_F64")) o->cull_f64 = 1;
     if (std::getenv("MLRT_NO_PAIR_WALK")) o->pair_walk = 0;
+    if (const char* sr = std::getenv("MLRT_SPLIT_ROLES")) o->split_roles = std::atoi(sr);
     if (const char* ts = std::getenv("MLRT_TILE_SAMPLES")) o->tile_samples = std::atoi(ts);
     if (const char* nq = std::getenv("MLRT_TILE_QUEUES")) o->tile_queues = std::atoi(nq);
     if (const char* spec = std::getenv("MLRT_TILE_TAIL")) {
@@ -1142,7 +1146,12 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         // references and the lanes' stacks fit the LDS; otherwise the threaded list below.
         size_t pair_stack_bytes = 0;
         auto take_pairs = [&](auto& Q) {
-            const size_t stack = (size_t)(Q.stack_levels + 1) * (size_t)c->block_threads * sizeof(int16_t);  // (mlrt_kernel.hip: one guard row below the stack)
+            size_t stack = (size_t)(Q.stack_levels + 1) * (size_t)c->block_threads * sizeof(int16_t);  // (mlrt_kernel.hip: one guard row below the stack)
+            // the split-role kernel: stacks for its traversal waves only, plus the control block and the two queues; used when that and
+            // the scene fit the LDS (its queues are what it is made of: no HBM form)
+            const size_t split_bytes = options->split_roles != 0 ? c->build->split_lds_bytes(Q.stack_levels) : 0;
+            const size_t lds_scene_part = c->build->lean_materials_in_hbm() ? (size_t)Q.off_materials : Q.blob.size();
+            if (split_bytes > 0 && lds_scene_part + lds_other + split_bytes <= lds_limit && options->lds_scene != 0) { stack = split_bytes; c->split_roles = true; }
             if (stack + lds_other + 1024 > lds_limit) return;  // (even with the scene in HBM the stacks must fit)
             blob.swap(Q.blob);
             const int32_t o[6] = {Q.off_pairs, Q.off_materials, (int32_t)blob.size(), (int32_t)blob.size(), (int32_t)blob.size(), (int32_t)blob.size()};

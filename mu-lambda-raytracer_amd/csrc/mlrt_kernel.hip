@@ -1462,6 +1462,14 @@ constexpr int full_block(uint32_t feat) {
     const int w = full_waves(feat);
     return w <= 4 ? w * 256 : w * 128;  // above 4 waves per SIMD: two workgroups per CU
 }
+// The split-role kernel (mlrt_split.inc) exists in the builds with f32 culling entries, like the pair walk it is built on.
+#ifndef MLRT_HAVE_SPLIT
+#ifdef MLRT_STRICT
+#define MLRT_HAVE_SPLIT 0
+#else
+#define MLRT_HAVE_SPLIT 1
+#endif
+#endif
 template <bool LDS_SCENE, uint32_t FEAT, int BLOCK, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FEAT == 0 ? MLRT_LEAN_WAVES_PER_EU : full_waves(FEAT))))
 void mlrt_render_kernel(const KParams<real> P) {
@@ -1926,6 +1934,10 @@ void mlrt_render_kernel(const KParams<real> P) {
     }
 }
 
+#if MLRT_HAVE_SPLIT
+#include "mlrt_split.inc"
+#endif
+
 // to_rgb (raytrace.rs:59-68) in f64 over the finished accumulation buffer.  The kernel also leaves the frame's scratch the
 // way the next frame wants to find it - the sums it has read and the tile counters zero - so a frame is three launches
 // and no memset (a 23 MB hipMemsetAsync per C2 frame does not shrink when a GPU renders 1/8 of the rows).
@@ -2170,6 +2182,19 @@ int occupancy_pair(size_t dyn_lds) {
     if constexpr (kCull32) return occupancy_variant<LDS, kLeanFeatures, MLRT_LEAN_BLOCK, true>(dyn_lds);
     else return -1;
 }
+// the split-role kernel over the pair structure (KParams::pair_walk == 2)
+template <bool LDS>
+int launch_split(const KParams<real>& P, int grid, size_t dyn_lds, hipStream_t stream) {
+#if MLRT_HAVE_SPLIT
+    if constexpr (kCull32) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlrt_split_kernel<LDS, MLRT_LEAN_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((mlrt_split_kernel<LDS, MLRT_LEAN_BLOCK>), dim3((unsigned)grid), dim3(MLRT_LEAN_BLOCK), dyn_lds, stream, P);
+        return (int)hipGetLastError();
+    }
+#endif
+    return (int)hipErrorInvalidValue;
+}
 }  // namespace MLRT_NS
 
 // variant: 0 = FULL, 1 = LEAN (threaded list), 2 = LEAN over the pair structure (KParams::pair_walk)
@@ -2183,7 +2208,8 @@ extern "C" int MLRT_CAT(mlrt_launch_, MLRT_SUFFIX)(const void* kparams, int vari
         rc = (int)hipGetLastError();
         if (rc != 0) return rc;
     }
-    if (variant == 2) rc = lds_scene ? MLRT_NS::launch_pair<true>(P, grid, dyn_lds, stream) : MLRT_NS::launch_pair<false>(P, grid, dyn_lds, stream);
+    if (variant == 2 && P.pair_walk == 2) rc = lds_scene ? MLRT_NS::launch_split<true>(P, grid, dyn_lds, stream) : MLRT_NS::launch_split<false>(P, grid, dyn_lds, stream);
+    else if (variant == 2) rc = lds_scene ? MLRT_NS::launch_pair<true>(P, grid, dyn_lds, stream) : MLRT_NS::launch_pair<false>(P, grid, dyn_lds, stream);
     else if (variant == 1) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream)
                                      : MLRT_NS::launch_variant<false, MLRT_NS::kLeanFeatures, MLRT_LEAN_BLOCK>(P, grid, dyn_lds, stream);
 #define MLRT_SUBSET_LAUNCH(k) else if (variant == 3 + k) rc = lds_scene ? MLRT_NS::launch_variant<true, MLRT_NS::kSubsetFeatures[k], MLRT_NS::full_block(MLRT_NS::kSubsetFeatures[k])>(P, grid, dyn_lds, stream) \
@@ -2218,6 +2244,16 @@ extern "C" int MLRT_CAT(mlrt_block_threads_, MLRT_SUFFIX)(int variant) {
     return (variant == 1 || variant == 2) ? MLRT_LEAN_BLOCK : MLRT_NS::full_block(MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(variant));
 }
 extern "C" int MLRT_CAT(mlrt_has_pair_walk_, MLRT_SUFFIX)(void) { return MLRT_NS::kCull32 ? 1 : 0; }
+// split-role kernel: bytes of LDS behind the frame parameters for a scene whose stacks need `stack_levels` rows (0: the build has no such kernel)
+extern "C" size_t MLRT_CAT(mlrt_split_lds_bytes_, MLRT_SUFFIX)(int stack_levels) {
+#if MLRT_HAVE_SPLIT
+    if (MLRT_NS::kCull32) {
+        const size_t stacks = (size_t)(stack_levels + 1) * (size_t)(MLRT_NS::split_t_waves(MLRT_LEAN_BLOCK) * 64) * sizeof(int16_t);
+        return ((stacks + 15) & ~(size_t)15) + MLRT_NS::split_queue_bytes();
+    }
+#endif
+    return 0;
+}
 extern "C" int MLRT_CAT(mlrt_acc_bytes_per_wave_, MLRT_SUFFIX)(int variant) { return MLRT_NS::acc_bytes_per_wave(MLRT_CAT(mlrt_variant_features_, MLRT_SUFFIX)(variant)); }
 extern "C" int MLRT_CAT(mlrt_lds_frame_bytes_, MLRT_SUFFIX)(void) { return MLRT_NS::kFrameParamBytes; }
 extern "C" int MLRT_CAT(mlrt_occupancy_, MLRT_SUFFIX)(int variant, int lds_scene, size_t dyn_lds) {

@@ -113,3 +113,21 @@ def test_max_depth_beyond_the_list_cursor_bits(mlrt):
         r.close()
         assert img.any() and np.array_equal(img, walked)
     w.close()
+
+
+@pytest.mark.parametrize("name,width,aspect,spp,aperture", [("random", 240, 1.5, 48, 0.0), ("random", 200, 1.5, 160, 0.1), ("simple", 160, 16.0 / 9.0, 32, 0.0)])
+def test_split_role_kernel_renders_the_same_sums(mlrt, name, width, aspect, spp, aperture):
+    """mlrt_options.split_roles (csrc/mlrt_split.inc: traversal waves and shading waves of a workgroup handing paths to each other through
+    two LDS queues; an experiment, off by default - it issues 1.8x the instructions of the one-role kernel, profiles/r03_experiment_split_roles*)
+    is the same arithmetic scheduled differently: f64 colour sums bit-equal to the one-role kernel's, both precisions; a frame large
+    enough for its queues to wrap many times."""
+    w = mlrt.World(name, 42)
+    height = mlrt.image_height(width, aspect)
+    cam = mlrt.default_camera(w, aspect, aperture, 10.0 if aperture else None)
+    params = mlrt.make_params(w, width, height, spp)
+    rows = np.arange(height, dtype=np.int32)
+    for precision in (mlrt.PRECISION_FP64, mlrt.PRECISION_FP32):
+        rgb0, acc0, _ = colour_sums(mlrt, w, cam, params, precision, rows)
+        rgb1, acc1, _ = colour_sums(mlrt, w, cam, params, precision, rows, opts=mlrt.options(split_roles=1))
+        assert acc0.any() and np.array_equal(acc0, acc1) and np.array_equal(rgb0, rgb1)
+    w.close()

@@ -26,7 +26,7 @@ def main():
             if "mlrt" not in k:
                 continue
             names.add(k.split("(")[0][:80])
-            (render if "mlrt_render_kernel" in k else other)[r["Counter_Name"]] += float(r["Counter_Value"])
+            (render if ("mlrt_render_kernel" in k or "mlrt_split_kernel" in k) else other)[r["Counter_Name"]] += float(r["Counter_Value"])
     g = lambda n: render.get(n, 0.0)
     cycles = g("GRBM_GUI_ACTIVE") / 8.0  # summed over the 8 XCDs
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
