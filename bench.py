@@ -47,7 +47,13 @@ CONFIGS = {
            "aperture": 0.0, "focus_dist": None, "baseline": "configs[4]", "metric": "Msamples/sec (pixels*spp) --world=final_scene 800x800 spp=10000 row-tiled"},
 }
 SIMDS, CLOCK_GHZ = 1024, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, max clock 2400 MHz
-VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32 (the guide's constants table)
+# What this chip sustains when measured (tools/microbench/valu_issue.hip under rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU,
+# profiles/r03_valu_issue_microbench.txt): 4.4-4.5 cycles per plain wave64 instruction per SIMD at 2, 4 and 8 waves per SIMD, f32 and f64
+# arithmetic alike (f32 transcendentals 8.4, f64 rcp / sqrt 16.2), whatever part of the wave is active.  4 cycles is the floor of that
+# measurement's model (a wave64 instruction = 4 passes of 16 lanes) and what the render kernels themselves reach.
+VALU_MEASURED_CYCLES = 4.0
+VALU_PEAK_MEASURED_GINSTR = SIMDS * CLOCK_GHZ / VALU_MEASURED_CYCLES
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Device fp32 record sizes of SURVEY 8(d)'s algorithmic-bytes figure
 REF_BYTES = {"aabb_tests": 32.0, "sphere_tests": 20.0, "rect_tests": 24.0, "scatters": 16.0, "noise_evals": 1008.0, "texel_fetches": 3.0}
@@ -125,10 +131,17 @@ def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
         out.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_insts_per_sample": per_sample,
                     "lane_utilisation": prof.get("lane_utilisation"), "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
                     "profile_frac_at_capture": prof.get("valu_issue_frac"), "traffic": prof.get("hbm_bytes_per_launch")})
+        # the same against the issue rate this chip was MEASURED to sustain (one plain wave64 instruction per 4 cycles per SIMD): at ~1.0 the
+        # kernel is bound by the number of vector instructions it issues, and only fewer instructions or fuller waves make it faster
+        out["peak_measured"] = VALU_PEAK_MEASURED_GINSTR
+        out["frac_of_measured_peak"] = achieved / VALU_PEAK_MEASURED_GINSTR
+        out["peak_measured_note"] = "profiles/r03_valu_issue_microbench.txt: 4.4-4.5 cycles per plain wave64 VALU instruction per SIMD measured (GRBM cycles / SQ_INSTS_VALU), " \
+                                    "any class, any occupancy >= 2 waves, any number of active lanes; %.0f cycles taken as the peak" % VALU_MEASURED_CYCLES
         if prof.get("lane_utilisation"):
             # issue slots that carried work: frac x the share of lanes active in an issued instruction; and the lane-level instruction
             # count per sample, which falls when instructions are removed and does NOT rise when idle lanes are added
             out["useful_frac"] = out["frac"] * prof["lane_utilisation"]
+            out["useful_frac_of_measured_peak"] = out["frac_of_measured_peak"] * prof["lane_utilisation"]
             out["valu_lane_insts_per_sample"] = per_sample * 64.0 * prof["lane_utilisation"]
         # the committed counters describe the build they were captured on: compare with the library about to be timed
         here, there = build_stamp(), prof.get("build_stamp")
