@@ -77,7 +77,18 @@ def cpu_baseline(cfg, cam19, height, seconds_budget=15.0):
         available = len(os.sched_getaffinity(0))
     except AttributeError:
         available = os.cpu_count() or 1
-    threads = max(1, available)  # every core this process may run on (the reference's rayon pool does the same: raytrace.rs:176)
+    # every core this process may run on (the reference's rayon pool does the same: raytrace.rs:176) - which is the smaller of the
+    # affinity mask and the container's CPU quota (cgroup cpu.max): on a GPU box whose mask shows 256 hardware threads but whose share
+    # is 16 cores, 256 threads run at a sixteenth of their speed each and the figure halves
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except Exception:
+        quota = None
+    threads = max(1, available if not quota else min(available, int(quota + 0.999)))
     w, spp = cfg["image_width"], cfg["samples_per_pixel"]
     us = CPU_US_PER_SAMPLE.get(cfg["world"], 5.0)
     sample_budget = seconds_budget * threads / (us * 1e-6)
@@ -90,7 +101,7 @@ def cpu_baseline(cfg, cam19, height, seconds_budget=15.0):
     _, _, stats, secs = ow.render(cam19, w, height, spp_cpu, seed=cfg["seed"], rng_mode=oracle_binding.RNG_PCG_ROW, rows=rows, threads=threads)
     ow.close()
     samples = len(rows) * w * spp_cpu
-    return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": threads, "cores_available": available, "kind": "port",
+    return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": threads, "cores_available": available, "cpu_quota": quota, "kind": "port",
             "sample": "%d evenly spaced rows of the %dx%d image at spp %d%s (%.1f Msamples, %.1f s), PCG64 row streams, f64 C++ restatement of the Rust reference"
                       % (len(rows), w, height, spp_cpu, "" if spp_cpu == spp else " (config: %d; cost is linear in spp)" % spp, samples / 1e6, secs),
             "stats_per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"}}
