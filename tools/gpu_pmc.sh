@@ -14,7 +14,7 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
             "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_BRANCH SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_ATOMIC" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  (cd $ROOT && rocprofv3 --pmc $pass --output-format csv -d $O/pass$i -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast --config $CFG --precision $PREC > $O/pass$i.log 2>&1) || { echo "pass $i failed"; tail -5 $O/pass$i.log; }
+  (cd $ROOT && rocprofv3 --pmc $pass --output-format csv -d $O/pass$i -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast --no-end-to-end --config $CFG --precision $PREC > $O/pass$i.log 2>&1) || { echo "pass $i failed"; tail -5 $O/pass$i.log; }
 done
 SAMPLES=$(python3 - <<PY
 import sys; sys.path.insert(0, "$ROOT")

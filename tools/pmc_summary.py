@@ -20,18 +20,29 @@ SIMDS = 1024
 def main():
     d, config, dtype, samples, prefix = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5]
     render, other, names = collections.defaultdict(float), collections.defaultdict(float), set()
+    launches = collections.defaultdict(set)  # counter -> dispatch ids of the render kernel it was read for
     for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "mlrt" not in k:
                 continue
             names.add(k.split("(")[0][:80])
-            (render if ("mlrt_render_kernel" in k or "mlrt_split_kernel" in k) else other)[r["Counter_Name"]] += float(r["Counter_Value"])
+            is_render = "mlrt_render_kernel" in k or "mlrt_split_kernel" in k
+            (render if is_render else other)[r["Counter_Name"]] += float(r["Counter_Value"])
+            if is_render:
+                launches[r["Counter_Name"]].add(r.get("Dispatch_Id", len(launches[r["Counter_Name"]])))
+    # a pass may hold several launches of the same frame (bench.py's end_to_end record renders it again): every figure below is PER LAUNCH
+    n_launch = max(1, min(len(v) for v in launches.values())) if launches else 1
+    if launches and len({len(v) for v in launches.values()}) != 1:
+        print("warning: passes hold different numbers of render launches:", {k: len(v) for k, v in launches.items()})
+    for table in (render, other):
+        for k in table:
+            table[k] /= n_launch
     g = lambda n: render.get(n, 0.0)
     cycles = g("GRBM_GUI_ACTIVE") / 8.0  # summed over the 8 XCDs
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from build_stamp import stamp
-    out = {"config": config, "dtype": dtype, "samples_per_launch": samples, "build_stamp": stamp(), "kernels": sorted(names),
+    out = {"config": config, "dtype": dtype, "samples_per_launch": samples, "render_launches_per_pass": n_launch, "build_stamp": stamp(), "kernels": sorted(names),
            "counters_render_kernel": dict(sorted(render.items())), "counters_prepass_and_resolve": dict(sorted(other.items()))}
     if g("SQ_INSTS_VALU"):
         out["valu_insts_per_sample"] = g("SQ_INSTS_VALU") / samples
@@ -62,7 +73,7 @@ def main():
         out["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
     json.dump(out, open(prefix + ".json", "w"), indent=1)
     with open(prefix + ".txt", "w") as f:
-        f.write("# rocprofv3 --pmc passes on ONE launch of %s (%s), render kernel only unless noted; tools/gpu_pmc.sh + tools/pmc_summary.py\n" % (config, dtype))
+        f.write("# rocprofv3 --pmc passes, per launch of %s (%s) (%d launches of the same frame per pass, averaged), render kernel only unless noted; tools/gpu_pmc.sh + tools/pmc_summary.py\n" % (config, dtype, n_launch))
         f.write("# build: lib sha256 %s, sources sha256 %s\n" % (out["build_stamp"]["lib_sha256"], out["build_stamp"]["source_sha256"]))
         for k, v in sorted(render.items()):
             f.write("%-32s %.6g\n" % (k, v))
