@@ -155,11 +155,12 @@ def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
             out["useful_frac_of_measured_peak"] = out["frac_of_measured_peak"] * prof["lane_utilisation"]
             out["valu_lane_insts_per_sample"] = per_sample * 64.0 * prof["lane_utilisation"]
         # the committed counters describe the build they were captured on: compare with the library about to be timed
+        # (hipcc's output is not bit-reproducible - two compiles of one source give two hashes - so the SOURCES decide staleness and the
+        # binary's hash is reported next to it: equal = the very file the counters were read from)
         here, there = build_stamp(), prof.get("build_stamp")
         out["profile_build"] = there
-        out["profile_stale"] = (not here) or (not there) or here.get("lib_sha256") != there.get("lib_sha256")
-        if out["profile_stale"] and here and there and here.get("source_sha256") == there.get("source_sha256"):
-            out["profile_stale_note"] = "the library was rebuilt from the same sources the profile was captured on"
+        out["profile_stale"] = (not here) or (not there) or here.get("source_sha256") != there.get("source_sha256")
+        out["profile_same_binary"] = bool(here and there and here.get("lib_sha256") == there.get("lib_sha256"))
         if prof.get("hbm_bytes_per_launch"):
             out["hbm_physical_GBps"] = prof["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
             out["hbm_physical_frac"] = out["hbm_physical_GBps"] / HBM_PEAK_GBS

@@ -5,7 +5,9 @@
 
 tools/pmc_summary.py writes the stamp into every profiles/*.json on the GPU box (which has no .git: the commit is added
 here, when the summary is copied into profiles/); bench.py compares it with the library it is about to time and reports
-roofline.profile_stale when they differ - the counters per sample in the committed summary then describe another kernel.
+roofline.profile_stale when the SOURCES differ - the counters per sample in the committed summary then describe another kernel -
+and roofline.profile_same_binary when even the binary is the one that was profiled (two hipcc runs on one source do not give the
+same bytes, so a rebuild changes the library's hash and nothing else).
 """
 import glob
 import hashlib
@@ -39,7 +41,8 @@ if __name__ == "__main__":
     for path in sys.argv[1:]:
         doc = json.load(open(path))
         st = doc.get("build_stamp") or {}
-        if st.get("lib_sha256") == here["lib_sha256"] and st.get("source_sha256") == here["source_sha256"]:
+        if st.get("source_sha256") == here["source_sha256"]:  # (same sources; hipcc's output is not bit-reproducible, so the binary may be a rebuild)
+            st["same_binary_as_checkout"] = st.get("lib_sha256") == here["lib_sha256"]
             st["git_head"] = head + ("+uncommitted" if dirty else "")
             doc["build_stamp"] = st
             json.dump(doc, open(path, "w"), indent=1)
