@@ -154,6 +154,9 @@ def roofline(config, dtype, my_samples, kernel_ms, cpu_stats, spp):
             out["useful_frac"] = out["frac"] * prof["lane_utilisation"]
             out["useful_frac_of_measured_peak"] = out["frac_of_measured_peak"] * prof["lane_utilisation"]
             out["valu_lane_insts_per_sample"] = per_sample * 64.0 * prof["lane_utilisation"]
+            # the floor of THIS instruction mix: the same lane-level work issued in full waves at the measured issue rate - what perfect
+            # packing of lanes would buy, and the yardstick a change that removes instructions moves
+            out["full_wave_floor_ms"] = kernel_ms * out["frac_of_measured_peak"] * prof["lane_utilisation"]
         # the committed counters describe the build they were captured on: compare with the library about to be timed
         # (hipcc's output is not bit-reproducible - two compiles of one source give two hashes - so the SOURCES decide staleness and the
         # binary's hash is reported next to it: equal = the very file the counters were read from)

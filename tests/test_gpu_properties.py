@@ -465,3 +465,26 @@ def test_one_context_renders_frames_of_changing_size_and_contexts_run_side_by_si
         renderers[k].close()
     for w in worlds.values():
         w.close()
+
+
+def test_every_world_runs_on_its_smallest_kernel_variant(mlrt, earthmap):
+    """The launcher picks the compiled kernel variant with the smallest feature set that covers the scene (csrc/mlrt_kernel.hip
+    kSubsetFeatures: one per reference world that is not sphere-only, by what worlds.rs builds); sphere-only worlds take the pair
+    structure.  A wrong pick would still render (variant 0 has every feature): this test is what keeps the lean ones in use."""
+    want = {"random": "lean-pair", "simple": "lean-pair", "cornell_box": "full-subset-0", "cornell_smoke": "full-subset-1", "final_scene": "full-subset-2",
+            "earth": "full-subset-3", "simple_light": "full-subset-4", "debug_perlin": "full-subset-5", "two_spheres": "full-subset-6", "random_chk": "full-subset-6"}
+    for name, variant in want.items():
+        w = mlrt.World(name, 42, earthmap if name in ("earth", "final_scene") else None)
+        cam = mlrt.default_camera(w, 1.0)
+        params = mlrt.make_params(w, 32, 32, 4)
+        for precision in (mlrt.PRECISION_FP64, mlrt.PRECISION_FP32):
+            r = mlrt.Renderer(w, cam, params, precision=precision)
+            img = r.render()
+            info = r.info()
+            r.close()
+            assert info["kernel_variant"] == variant, (name, precision, info)
+            assert img.shape == (32, 32, 3)
+        r = mlrt.Renderer(w, cam, params, precision=mlrt.PRECISION_FP64, opts=mlrt.options(force_full=1))
+        assert r.info()["kernel_variant"] == "full"
+        r.close()
+        w.close()
