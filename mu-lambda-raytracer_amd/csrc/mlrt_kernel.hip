@@ -2154,7 +2154,7 @@ constexpr uint32_t kLeanFeatures = 0;
 // Variants 3 .. 3 + kSubsets - 1: the FULL kernel compiled for a subset of the scene features (mlrt_device.hpp FEAT_*) - the dead branches
 // of the others leave the loop and the registers they held with them.  One per reference world that is not sphere-only, by what its
 // builder creates (worlds.rs): cornell_box (:244-290), cornell_smoke (:292-338), final_scene (:368-469: everything but a Checker),
-// earth (:165-189), simple_light (:214-242), debug_perlin (:191-212), two_spheres / random_chk (:115-163).  The host picks the
+// earth (:165-189), simple_light (:214-242), two_spheres and debug_perlin (:191-212, :339-366: Noise), random_chk (:115-163: Checker).  The host picks the
 // smallest compiled superset of a scene's features (variant 0 = all of them).
 constexpr int kSubsets = 7;
 constexpr uint32_t kSubsetFeatures[kSubsets] = {

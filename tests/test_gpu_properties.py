@@ -472,7 +472,7 @@ def test_every_world_runs_on_its_smallest_kernel_variant(mlrt, earthmap):
     kSubsetFeatures: one per reference world that is not sphere-only, by what worlds.rs builds); sphere-only worlds take the pair
     structure.  A wrong pick would still render (variant 0 has every feature): this test is what keeps the lean ones in use."""
     want = {"random": "lean-pair", "simple": "lean-pair", "cornell_box": "full-subset-0", "cornell_smoke": "full-subset-1", "final_scene": "full-subset-2",
-            "earth": "full-subset-3", "simple_light": "full-subset-4", "debug_perlin": "full-subset-5", "two_spheres": "full-subset-6", "random_chk": "full-subset-6"}
+            "earth": "full-subset-3", "simple_light": "full-subset-4", "debug_perlin": "full-subset-5", "two_spheres": "full-subset-5", "random_chk": "full-subset-6"}
     for name, variant in want.items():
         w = mlrt.World(name, 42, earthmap if name in ("earth", "final_scene") else None)
         cam = mlrt.default_camera(w, 1.0)
