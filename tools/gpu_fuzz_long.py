@@ -55,5 +55,9 @@ for seed in range(first, first + count):
     if frac > 5e-4: print("seed", seed, "LEAN frame fp64 frac %.2e rmse %.2e" % (frac, rmse), flush=True); bad_total += 1
     other, _, _ = fz.render_scene_both(rel, orc, scene3, cam, w, h, spp, 50 if seed % 5 else 3, 2000 + seed, 1, rel.PRECISION_FP64, opts=rel.options(primary_lists=0))
     if not np.array_equal(other, got): print("seed", seed, "LEAN frame: candidate lists change the image", flush=True); bad_total += 1
+    # round 3: the same frame over the threaded list instead of the pair structure, and through the split-role kernel
+    for label, o2 in (("threaded list", rel.options(pair_walk=0)), ("split roles", rel.options(split_roles=1))):
+        other, _, _ = fz.render_scene_both(rel, orc, scene3, cam, w, h, spp, 50 if seed % 5 else 3, 2000 + seed, 1, rel.PRECISION_FP64, opts=o2)
+        if not np.array_equal(other, got): print("seed", seed, "LEAN frame: %s changes the image" % label, flush=True); bad_total += 1
     if seed % 10 == 9: print("... through seed", seed, "%.0f s" % (time.time() - t0), "disagreements so far:", bad_total, flush=True)
 print("done:", count, "seeds,", bad_total, "disagreements")
