@@ -1567,6 +1567,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         }
     };
     unsigned int st_psteps = 0, st_pspecial = 0;  // MLRT_STATS: traversal steps / special entries of primary rays
+    unsigned long long st_wait = 0ull;            // MLRT_STATS: lane-iterations spent starved (PH_WAIT: the wave's banks are all taken and its tile is handed out)
     unsigned long long st_c_trav = 0, st_c_special = 0, st_c_shade = 0, st_c0 = 0;  // MLRT_STATS: shader clocks per loop section
     unsigned long long st_c_end = 0, st_c_regen = 0, st_c1 = 0;  // MLRT_STATS: within the shading batch: paths ended/scattered, regeneration (the rest: new-ray setup)
     unsigned int st_iter = 0, st_steps = 0, st_sb = 0, st_sl = 0, st_hb = 0, st_hl = 0, st_samples = 0, st_tiles = 0;  // MLRT_STATS
@@ -1628,7 +1629,8 @@ void mlrt_render_kernel(const KParams<real> P) {
 #pragma unroll
         for (int sub = 0; sub < (PAIR ? MLRT_PAIR_STEPS : MLRT_STEPS); sub++) {
         pin_entry(n);
-        if (MLRT_STATS_ON(P)) { st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth)); }
+        if (MLRT_STATS_ON(P)) { st_steps += (unsigned int)__popcll(__ballot(phase == PH_TRAV)); st_psteps += (unsigned int)__popcll(__ballot(phase == PH_TRAV && depth == P.max_depth));
+                                 st_wait += (unsigned long long)__popcll(__ballot(phase == PH_WAIT)); }
         // The array ends in a TAG_END sentinel, so there is no bounds test.  Two shapes of the same step (measured): the
         // sphere-only variant runs at 6 waves per SIMD and is bound by vector-instruction issue, where two nested
         // branches cost fewer vector instructions than selects; the full variant (4 waves, box entries resolved in the
@@ -1935,6 +1937,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         atomicAdd(&P.stats[11], (unsigned long long)st_psteps); atomicAdd(&P.stats[12], (unsigned long long)st_pspecial);
         atomicAdd(&P.stats[8], st_c_trav); atomicAdd(&P.stats[9], st_c_special); atomicAdd(&P.stats[10], st_c_shade);
         atomicAdd(&P.stats[13], st_c_end); atomicAdd(&P.stats[14], st_c_regen);
+        atomicAdd(&P.stats[15], st_wait);
     }
 }
 

@@ -32,6 +32,7 @@ def run(name, W, aspect, spp, reps=3, aperture=0.0, focus=None):
             print('   primary rays: %.1f trav lane-steps/sample, %.2f specials/sample' % (int(st[11]) / samples, int(st[12]) / samples), flush=True)
             print('   shader clocks per wave-iteration: trav %.0f  special %.0f (%.0f per batch)  shade %.0f (%.0f per batch); share trav %.2f special %.2f shade %.2f' % (ct / it, cs / it, cs / max(sb, 1), ch / it, ch / max(hb, 1), ct / (ct + cs + ch), cs / (ct + cs + ch), ch / (ct + cs + ch)), flush=True)
             print('   inside a shading batch: end/scatter %.0f clocks, regeneration %.0f, new-ray setup %.0f' % (int(st[13]) / max(hb, 1), int(st[14]) / max(hb, 1), (ch - int(st[13]) - int(st[14])) / max(hb, 1)), flush=True)
+            print('   starved lanes (PH_WAIT: no bank free for another tile): %.3f of all lane-iterations; tiles %d, samples/tile %.0f' % (int(st[15]) / (it * 64.0), tiles, samples / max(tiles, 1)), flush=True)
             print('   stats over %d renders: iters/sample %.2f  trav lane-steps/sample %.1f  TRAV util %.3f | special batches: %.2f lanes avg, %.2f specials/sample | shade batches: %.2f lanes avg, %.2f shades/sample' % (reps + 1, it / samples * 64 / 64, steps / samples, steps / (it * 64.0 * STEPS_PER_ITER), sl / max(sb, 1), sl / samples, hl / max(hb, 1), hl / samples), flush=True)
     r.close(); w.close()
 
