@@ -178,9 +178,19 @@ typedef struct mlrt_params {
                                                            * stream keyed by this seed - same distributions, image deterministic and
                                                            * independent of how rows are spread over GPUs ("RNG contract") */
     int32_t background_kind;                              /* MLRT_BG_* */
-    int32_t _pad;
+    int32_t tracer;                                       /* MLRT_TRACER_*: the Renderer's RayTracer (raytrace.rs:70-72, 137-141).  0 = the
+                                                           * path tracer, as main.rs:150-152 constructs it */
     double background_top[3], background_bottom[3]; /* GradientBackground, raytrace.rs:12-35 */
+    double light_source[3];                         /* MLRT_TRACER_SINGLE_LIGHT: SingleLightSourceRayTracer::light_source, */
+    double light_intensity;                         /*   ::intensity (raytrace.rs:110-113; main.rs:153 has (14, 3, 3) and 1.0) */
 } mlrt_params;
+/* RecursiveRayTracer { max_depth } (raytrace.rs:74-108) */
+#define MLRT_TRACER_RECURSIVE 0
+/* SingleLightSourceRayTracer { light_source, intensity } (raytrace.rs:110-135): one bounce.  A hit whose material scatters is shaded
+ * attenuation * intensity * max(l.n, 0) + 0.5 * intensity * max(h.n, 0)^100 towards the point light (the scattered ray is dropped, its
+ * RNG draws are made); one that does not scatter emits; a miss is the background.  max_depth is not used.  Needs a context created with
+ * mlrt_options.single_light_tracer = 1 (mlrt_render / mlrt_render_multi set it themselves); MLRT_ERR_UNSUPPORTED otherwise. */
+#define MLRT_TRACER_SINGLE_LIGHT 1
 
 /* Called on the calling thread after each finished band of rows (coarser than the reference's per-row
  * logger, raytrace.rs:182; main.rs:157-173 only derives a throttled percentage from it). */
@@ -211,6 +221,8 @@ typedef struct mlrt_options {
     int32_t split_roles;   /* 1: sphere-only scenes on the pair structure are rendered by the split-role kernel - traversal waves and shading
                             * waves of a workgroup handing paths to each other through two queues in LDS - when its queues fit the LDS next to
                             * the scene; 0: every wave does everything.  Same image either way. */
+    int32_t single_light_tracer; /* 1: the context can also render with MLRT_TRACER_SINGLE_LIGHT (it then runs the all-features kernel
+                            * variant, the one that carries that tracer's shading, whatever the scene holds); 0 (default): path tracer only */
 } mlrt_options;
 void mlrt_options_default(mlrt_options* out);
 /* The defaults overridden by the MLRT_* environment variables (MLRT_NO_SAH, MLRT_NO_LEAF_WRAP, MLRT_NO_PRIMARY_LISTS,

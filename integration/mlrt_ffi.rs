@@ -42,7 +42,8 @@ pub const MLRT_GATHER_AUTO: i32 = 0;
 #[repr(C)] pub struct MlrtCamera { pub origin: [f64; 3], pub lower_left_corner: [f64; 3], pub horizontal: [f64; 3], pub vertical: [f64; 3],
                                    pub u: [f64; 3], pub v: [f64; 3], pub lens_radius: f64 }                               // camera.rs:3-12
 #[repr(C)] pub struct MlrtParams { pub image_width: i32, pub image_height: i32, pub samples_per_pixel: i32, pub max_depth: i32, pub seed: u64,
-                                   pub background_kind: i32, pub _pad: i32, pub background_top: [f64; 3], pub background_bottom: [f64; 3] }
+                                   pub background_kind: i32, pub tracer: i32 /* 0 RecursiveRayTracer, 1 SingleLightSourceRayTracer */,
+                                   pub background_top: [f64; 3], pub background_bottom: [f64; 3], pub light_source: [f64; 3], pub light_intensity: f64 }
 #[repr(C)] pub struct MlrtContext { _private: [u8; 0] }
 #[repr(C)] pub struct MlrtMulti { _private: [u8; 0] }
 pub type MlrtProgress = Option<extern "C" fn(rows_done: i32, rows_total: i32, user: *mut c_void)>;

@@ -99,15 +99,18 @@ class CameraStruct(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
-                ("seed", C.c_uint64), ("background_kind", C.c_int32), ("_pad", C.c_int32), ("background_top", C.c_double * 3),
-                ("background_bottom", C.c_double * 3)]
+                ("seed", C.c_uint64), ("background_kind", C.c_int32), ("tracer", C.c_int32), ("background_top", C.c_double * 3),
+                ("background_bottom", C.c_double * 3), ("light_source", C.c_double * 3), ("light_intensity", C.c_double)]
+
+
+TRACER_RECURSIVE, TRACER_SINGLE_LIGHT = 0, 1
 
 
 class Options(C.Structure):
     """mlrt_options (include/mlrt.h): tuning / diagnostic switches, none of which may change an f64 image."""
     _fields_ = [("sah", C.c_int32), ("leaf_wrap", C.c_int32), ("primary_lists", C.c_int32), ("lds_scene", C.c_int32), ("force_full", C.c_int32), ("cull_f64", C.c_int32),
                 ("tile_samples", C.c_int32), ("tile_queues", C.c_int32), ("n_tail", C.c_int32), ("tail", C.c_int32 * 8), ("stats", C.c_int32),
-                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32), ("pair_walk", C.c_int32), ("split_roles", C.c_int32)]
+                ("debug_pixel", C.c_int32), ("debug_sample", C.c_int32), ("stall_cap", C.c_int32), ("pair_walk", C.c_int32), ("split_roles", C.c_int32), ("single_light_tracer", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
@@ -276,11 +279,17 @@ def camera_new(lookfrom, lookat, vup, vfov, aspect_ratio, aperture, focus_dist):
     return out
 
 
-def make_params(world, image_width, image_height, samples_per_pixel, max_depth=50, seed=None):
+def make_params(world, image_width, image_height, samples_per_pixel, max_depth=50, seed=None, single_light=None):
+    """single_light = (light_source xyz, intensity): SingleLightSourceRayTracer instead of RecursiveRayTracer{max_depth} (raytrace.rs:110-135)."""
     p = Params()
     p.image_width, p.image_height, p.samples_per_pixel, p.max_depth = int(image_width), int(image_height), int(samples_per_pixel), int(max_depth)
     p.seed = world.seed if seed is None else int(seed)
     world.background(p)
+    if single_light is not None:
+        p.tracer = TRACER_SINGLE_LIGHT
+        for k in range(3):
+            p.light_source[k] = float(single_light[0][k])
+        p.light_intensity = float(single_light[1])
     return p
 
 
@@ -298,6 +307,8 @@ class Renderer:
     def __init__(self, world, camera, params, precision=PRECISION_FP32, device=0, opts=None):
         self.world, self.camera, self.params, self.precision, self.device = world, camera, params, precision, device
         ctx = C.c_void_p()
+        if opts is None and params.tracer == TRACER_SINGLE_LIGHT:
+            opts = options(single_light_tracer=1)  # (the context must carry that tracer's kernel variant, include/mlrt.h)
         if opts is None:
             _check(lib().mlrt_context_create(world.scene, int(device), int(precision), C.byref(ctx)))
         else:

@@ -877,10 +877,13 @@ void fill_params(const mlrt_context* c, const mlrt_camera* cam, const mlrt_param
         K.bg_top[k] = (R)p->background_top[k]; K.bg_bottom[k] = (R)p->background_bottom[k];
     }
     K.lens_radius = cam->lens_radius;
-    K.has_lens = (cam->lens_radius != 0.0 ? 1 : 0) | (c->d_ray_table ? 2 : 0);
+    const bool single_light = p->tracer == MLRT_TRACER_SINGLE_LIGHT;
+    K.has_lens = (cam->lens_radius != 0.0 ? 1 : 0) | (c->d_ray_table ? 2 : 0) | (single_light ? 4 : 0);
     K.ray_table = c->d_ray_table;
+    for (int k = 0; k < 3; k++) K.single_light[k] = p->light_source[k];
+    K.single_light[3] = p->light_intensity;
     K.inv_wm1 = 1.0 / ((double)p->image_width - 1.0); K.inv_hm1 = 1.0 / ((double)p->image_height - 1.0);
-    K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = p->max_depth;
+    K.width = p->image_width; K.height = p->image_height; K.spp = p->samples_per_pixel; K.max_depth = single_light ? 1 : p->max_depth;  // (SingleLightSourceRayTracer has no depth: one bounce)
     K.seed_lo = (uint32_t)p->seed; K.seed_hi = (uint32_t)(p->seed >> 32);
     K.bg_kind = p->background_kind;
     K.rows = d_rows; K.n_rows = n_rows;
@@ -922,6 +925,9 @@ void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) 
     MLRT_REQUIRE(n_rows >= 0 && n_rows <= p->image_height, "n_rows out of range");
     MLRT_REQUIRE((int64_t)n_rows * p->image_width * 3 < (int64_t)1 << 31, "frame too large: n_rows * width * 3 must stay below 2^31 (32-bit indices of the accumulation buffer)");
     MLRT_REQUIRE(p->background_kind == MLRT_BG_BLACK || p->background_kind == MLRT_BG_GRADIENT, "unknown background kind");
+    MLRT_REQUIRE(p->tracer == MLRT_TRACER_RECURSIVE || p->tracer == MLRT_TRACER_SINGLE_LIGHT, "unknown tracer");
+    if (p->tracer == MLRT_TRACER_SINGLE_LIGHT)
+        for (int k = 0; k < 4; k++) MLRT_REQUIRE(std::fabs(k < 3 ? p->light_source[k] : p->light_intensity) < 0x1p100, "light_source / light_intensity is not finite (or is 2^100 or more)");
     // (a camera of NaNs renders NaNs in the reference too; refused here like non-finite geometry, with the same bound on magnitudes)
     const double* c = cam->origin;
     static_assert(sizeof(mlrt_camera) == 19 * sizeof(double), "mlrt_camera is 19 doubles");
@@ -935,6 +941,8 @@ void check_params(const mlrt_camera* cam, const mlrt_params* p, int32_t n_rows) 
 void launch(mlrt_context* c, const mlrt_camera* cam, const mlrt_params* p, const int32_t* d_rows, int32_t n_rows, int32_t* d_rgb, double* d_accum,
             hipStream_t stream) {
     if (n_rows == 0) return;
+    if (p->tracer == MLRT_TRACER_SINGLE_LIGHT && c->variant != 0)
+        throw Fail{MLRT_ERR_UNSUPPORTED, "MLRT_TRACER_SINGLE_LIGHT needs a context created with mlrt_options.single_light_tracer = 1 (the all-features kernel variant carries that tracer)"};
     MLRT_HIP(hipSetDevice(c->device));
     const size_t need = (size_t)n_rows * (size_t)p->image_width * 3;
     if (need > c->acc_elems) {
@@ -1054,7 +1062,7 @@ int32_t mlrt_device_count(void) {
 void mlrt_options_default(mlrt_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);
-    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0; o->pair_walk = 1; o->split_roles = 0;
+    o->sah = 1; o->leaf_wrap = 1; o->primary_lists = 1; o->lds_scene = 1; o->force_full = 0; o->cull_f64 = 0; o->pair_walk = 1; o->split_roles = 0; o->single_light_tracer = 0;
     o->tile_samples = 512; o->tile_queues = 8; o->n_tail = -1;
     o->stats = 0; o->debug_pixel = -1; o->debug_sample = 0; o->stall_cap = 0;
 }
@@ -1117,8 +1125,9 @@ int32_t mlrt_context_create_opts(const mlrt_scene* scene, int32_t device, int32_
         // the leanest compiled kernel variant that covers the scene's features
         c->features = scene_features(*scene);
         const uint32_t lean = c->build->variant_features(1);
-        c->variant = ((c->features & ~lean) == 0 && !options->force_full) ? 1 : 0;
-        if (c->variant == 0 && !options->force_full) {
+        const bool all_features = options->force_full != 0 || options->single_light_tracer != 0;
+        c->variant = ((c->features & ~lean) == 0 && !all_features) ? 1 : 0;
+        if (c->variant == 0 && !all_features) {
             // the FULL kernel compiled for the smallest superset of the scene's features (variant 0 has them all)
             auto bits = [](uint32_t f) { int n = 0; for (; f; f &= f - 1) n++; return n; };
             for (int v = 3; v < c->build->variant_count(); v++) {
@@ -1400,7 +1409,10 @@ int32_t mlrt_debug_stats(mlrt_context* ctx, unsigned long long out[16]) {
 int32_t mlrt_render(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision, int32_t* rgb_out,
                     mlrt_progress_fn progress, void* user) {
     mlrt_context* ctx = nullptr;
-    int32_t rc = mlrt_context_create(scene, 0, precision, &ctx);
+    mlrt_options o;
+    mlrt_options_from_env(&o);
+    if (params && params->tracer == MLRT_TRACER_SINGLE_LIGHT) o.single_light_tracer = 1;
+    int32_t rc = mlrt_context_create_opts(scene, 0, precision, &o, &ctx);
     if (rc != MLRT_OK) return rc;
     rc = mlrt_context_render(ctx, camera, params, nullptr, 0, rgb_out, progress, user);
     mlrt_context_destroy(ctx);

@@ -140,7 +140,7 @@ struct KParams {
     double cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
     double lens_radius;
     double inv_wm1, inv_hm1;  // 1 / (width - 1), 1 / (height - 1)  (cam_origin ... inv_hm1 stay contiguous: the kernel copies them as 21 doubles)
-    int32_t has_lens;    // bit 0: lens_radius != 0; bit 1: ray_table is set (a ray frame)
+    int32_t has_lens;    // bit 0: lens_radius != 0; bit 1: ray_table is set (a ray frame); bit 2: MLRT_TRACER_SINGLE_LIGHT
     int32_t width, height, spp, max_depth;
     uint32_t seed_lo, seed_hi;
     int32_t bg_kind;
@@ -173,6 +173,9 @@ struct KParams {
     // direction xyz) instead of the camera's ray - the sample's Philox block 0 is consumed as always.  Read from the kernel-argument
     // segment at its one point of use (gen_camera_ray); kept last so that no other field moves.
     const double* ray_table;
+    // MLRT_TRACER_SINGLE_LIGHT (has_lens bit 2, all-features variant only): light_source xyz and intensity, read from the kernel-argument
+    // segment where a hit is shaded
+    double single_light[4];
 };
 
 }  // namespace mlrt

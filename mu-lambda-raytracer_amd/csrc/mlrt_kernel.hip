@@ -1180,6 +1180,34 @@ DEV const double* ray_table_pointer() {
     return nullptr;
 #endif
 }
+// SingleLightSourceRayTracer::trace after a scatter (raytrace.rs:119-126): Lambert and Blinn-Phong terms towards one point light.
+// `view` = -ray.dir.unit() of the ray that hit, taken before the scatter replaced it; `attenuation` = the scatter's.  The light is read
+// from the kernel-argument segment here (KParams::single_light): the path tracer's frames do not carry it in registers.  The f64 builds
+// keep the reference's operation order (powi(100) as compiler-rt's square-and-multiply from the low bit); the f32 build computes in f32.
+DEV V3 single_light_colour(V3 attenuation, const HitAttr& hit, V3 view) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double* q = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KParams<real>, single_light));
+    const double lx = q[0], ly = q[1], lz = q[2];
+    const real intensity = (real)q[3];
+#else
+    const double lx = 0, ly = 0, lz = 0;
+    const real intensity = 0;
+#endif
+    const V3 l = unit(to_v3(mkp(lx, ly, lz) - hit.p));
+    const V3 h = unit(l + view);
+    const real kd = dot(l, hit.normal), ks = dot(h, hit.normal);
+    real a = ks > (real)0 ? ks : (real)0, r = (real)1;  // f64::max(x, 0.0): a NaN becomes 0
+#pragma unroll
+    for (int n = 100;;) {
+        if (n & 1) r *= a;
+        n /= 2;
+        if (n == 0) break;
+        a *= a;
+    }
+    const V3 lambertian = (attenuation * intensity) * (kd > (real)0 ? kd : (real)0);
+    const V3 blinn_phong = (mk((real)0.5, (real)0.5, (real)0.5) * intensity) * r;
+    return lambertian + blinn_phong;
+}
 // raytrace.rs:191-193 + Camera::get_ray, camera.rs:40-48, in f64 in both builds: the uniforms are 24-bit values
 // exact in either precision, so the primary ray is bit-identical to the oracle's (parity build; the fast build
 // evaluates the lens offset's sin/cos in f32).  A fresh sample's four draws - u, v and the lens sample, drawn by
@@ -1786,9 +1814,17 @@ void mlrt_render_kernel(const KParams<real> P) {
                     if (!kWaveNoise) h = hit_attributes<FEAT, PAIR>(S, c, o, d);
                     V3 emitted = mk(0, 0, 0);
                     const V3 texture_colour = material_texture<FEAT>(S, h, have_turbulence, turbulence);
+                    // the Renderer's other RayTracer (MLRT_TRACER_SINGLE_LIGHT; all-features variant only, wave-uniform): one bounce
+                    const bool single_light = FEAT == FEAT_ALL && !PAIR && (P.has_lens & 4) != 0;
+                    V3 view = mk(0, 0, 0);
+                    if (MLRT_RARELY(single_light)) view = -unit(to_v3(d));
                     if (scatter<FEAT>(S, h, texture_colour, o, d, thr, emitted, g, key, P.max_depth - depth)) {
+                        if (MLRT_RARELY(single_light)) {
+                            radiance = single_light_colour(thr, h, view);  // (a primary ray's throughput is 1: thr is the attenuation)
+                        } else {
                         depth--;
                         if (depth > 0) { done = false; new_ray = true; }  // depth <= 0: raytrace.rs:87-89, radiance 0
+                        }
                     } else {
                         radiance = thr * emitted;
                     }

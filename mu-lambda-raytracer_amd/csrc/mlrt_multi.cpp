@@ -360,7 +360,10 @@ int32_t mlrt_multi_info(mlrt_multi* m, double* frame_ms, double* kernel_ms_per_d
 int32_t mlrt_render_multi(const mlrt_scene* scene, const mlrt_camera* camera, const mlrt_params* params, int32_t precision, const int32_t* devices,
                           int32_t n_devices, int32_t* rgb_out, mlrt_progress_fn progress, void* user) {
     mlrt_multi* m = nullptr;
-    int32_t rc = mlrt_multi_create(scene, devices, n_devices, precision, nullptr, MLRT_GATHER_AUTO, &m);
+    mlrt_options o;
+    mlrt_options_from_env(&o);
+    if (params && params->tracer == MLRT_TRACER_SINGLE_LIGHT) o.single_light_tracer = 1;
+    int32_t rc = mlrt_multi_create(scene, devices, n_devices, precision, &o, MLRT_GATHER_AUTO, &m);
     if (rc != MLRT_OK) return rc;
     rc = mlrt_multi_render(m, camera, params, rgb_out, progress, user);
     mlrt_multi_destroy(m);

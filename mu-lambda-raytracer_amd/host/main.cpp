@@ -128,7 +128,8 @@ int fail(const char* what) {
 int main(int argc, char** argv) {
     std::map<std::string, std::string> opt = {{"aspect_ratio", "16:9"}, {"image_width", "400"}, {"samples_per_pixel", "200"}, {"max_depth", "50"},
                                               {"up", "0,1.0,0"},        {"aperture", "0.0"},    {"world", "simple"},          {"precision", "fp64"},
-                                              {"device", "0"},          {"format", "p3"}};
+                                              {"device", "0"},          {"format", "p3"},       {"tracer", "recursive"},
+                                              {"light_source", "14.0,3.0,3.0"}, {"light_intensity", "1.0"}};
     bool randomized_rendering = false;
     for (int i = 1; i < argc; i++) {
         std::string a(argv[i]);
@@ -168,6 +169,17 @@ int main(int argc, char** argv) {
     params.samples_per_pixel = std::atoi(opt["samples_per_pixel"].c_str());
     params.max_depth = std::atoi(opt["max_depth"].c_str());
     params.seed = render_seed;
+    // The Renderer's RayTracer: main.rs:150-153 constructs RecursiveRayTracer{max_depth} and keeps SingleLightSourceRayTracer{(14, 3, 3), 1.0}
+    // in a comment - a recompile there, a flag here (its light defaults to that comment's).
+    if (opt["tracer"] != "recursive" && opt["tracer"] != "single_light") { std::fprintf(stderr, "mlrt: --tracer must be recursive or single_light\n"); return 2; }
+    mlrt_options options;
+    mlrt_options_from_env(&options);
+    if (opt["tracer"] == "single_light") {
+        params.tracer = MLRT_TRACER_SINGLE_LIGHT;
+        options.single_light_tracer = 1;
+        if (!parse_vector(opt["light_source"], params.light_source)) { std::fprintf(stderr, "mlrt: bad --light_source\n"); return 2; }
+        params.light_intensity = std::atof(opt["light_intensity"].c_str());
+    }
 
     std::vector<uint8_t> earth;
     int ew = 0, eh = 0;
@@ -255,7 +267,7 @@ int main(int argc, char** argv) {
         const double phi = std::atan2(dy, dx);
         const double grad = 3.141592653589793 / 180.0;  // movie.py:62 (math.pi)
         mlrt_context* mctx = nullptr;
-        if (mlrt_context_create(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &mctx) != MLRT_OK) return fail("context");
+        if (mlrt_context_create_opts(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &options, &mctx) != MLRT_OK) return fail("context");
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < frames; i++) {
             // movie.py:41-46 polar_to_cart, :64-69
@@ -285,10 +297,10 @@ int main(int argc, char** argv) {
     mlrt_context* ctx = nullptr;
     mlrt_multi* multi = nullptr;
     if (!devices.empty()) {
-        if (mlrt_multi_create(mlrt_world_scene(world), devices.data(), (int32_t)devices.size(), precision, nullptr, MLRT_GATHER_AUTO, &multi) != MLRT_OK) return fail("multi-device context");
+        if (mlrt_multi_create(mlrt_world_scene(world), devices.data(), (int32_t)devices.size(), precision, &options, MLRT_GATHER_AUTO, &multi) != MLRT_OK) return fail("multi-device context");
         if (mlrt_multi_render(multi, &camera, &params, rgb.data(), show_progress ? on_progress : nullptr, &progress) != MLRT_OK) return fail("render");
     } else {
-        if (mlrt_context_create(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &ctx) != MLRT_OK) return fail("context");
+        if (mlrt_context_create_opts(mlrt_world_scene(world), std::atoi(opt["device"].c_str()), precision, &options, &ctx) != MLRT_OK) return fail("context");
         if (mlrt_context_render(ctx, &camera, &params, nullptr, 0, rgb.data(), show_progress ? on_progress : nullptr, &progress) != MLRT_OK) return fail("render");
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - progress.start).count();

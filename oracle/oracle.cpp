@@ -287,6 +287,13 @@ struct RenderJob {
     int width, height, spp, max_depth;
     uint64_t seed;
     int rng_mode;
+    bool single_light = false;  // the RayTracer of the Renderer: RecursiveRayTracer{max_depth} or SingleLightSourceRayTracer{light_source, intensity}
+    Point3 light_source;
+    double intensity = 0.0;
+    Color trace(const Ray& r, Rng& rng) const {  // RayTracer::trace, raytrace.rs:70-72
+        return single_light ? trace_single_light(r, *world->root, world->background, light_source, intensity, rng)
+                            : trace_internal(r, *world->root, world->background, max_depth, rng);
+    }
     std::vector<int> rows;   // rows to render (j = 0 is the bottom row)
     int32_t* rgb;            // [H][W][3] (only listed rows are written)
     double* accum;           // optional [H][W][3] colour sums
@@ -301,13 +308,13 @@ static void render_pixel(const RenderJob& job, int i, int j, Rng* row_rng) {  //
             double u = ((double)i + row_rng->gen_range(0.0, 1.0)) / wm1;
             double v = ((double)j + row_rng->gen_range(0.0, 1.0)) / hm1;
             Ray r = job.camera.get_ray(u, v, *row_rng);
-            pixel_color = pixel_color + trace_internal(r, *job.world->root, job.world->background, job.max_depth, *row_rng);
+            pixel_color = pixel_color + job.trace(r, *row_rng);
         } else {
             PhiloxStream rng(job.seed, (uint32_t)(j * job.width + i), (uint32_t)s);
             double u = ((double)i + rng.gen_range(0.0, 1.0)) / wm1;
             double v = ((double)j + rng.gen_range(0.0, 1.0)) / hm1;
             Ray r = job.camera.get_ray(u, v, rng);
-            pixel_color = pixel_color + trace_internal(r, *job.world->root, job.world->background, job.max_depth, rng);
+            pixel_color = pixel_color + job.trace(r, rng);
         }
     }
     size_t idx = ((size_t)j * job.width + i) * 3;
@@ -538,8 +545,9 @@ void orc_trace_ray(void* h, const double o[3], const double d[3], int max_depth,
 // stats_out: optional 10 uint64: samples, rays, aabb, sphere, rect, scatters, draws, noise, texel, medium.
 // Returns the render wall time in seconds (the reference's timer window, main.rs:145-174).
 static double render_world(const World* world, const double camera19[19], int width, int height, int spp, int max_depth, uint64_t seed, int rng_mode,
-                           const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out) {
+                           const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out, const double* single_light = nullptr) {
     RenderJob job;
+    if (single_light) { job.single_light = true; job.light_source = Point3(single_light[0], single_light[1], single_light[2]); job.intensity = single_light[3]; }
     job.world = world;
     const double* c = camera19;
     job.camera.origin = Point3(c[0], c[1], c[2]);
@@ -568,6 +576,17 @@ static double render_world(const World* world, const double camera19[19], int wi
 double orc_render(void* h, const double camera19[19], int width, int height, int spp, int max_depth, uint64_t seed, int rng_mode,
                   const int* rows, int n_rows, int threads, int32_t* rgb, double* accum, uint64_t* stats_out) {
     return render_world(((OrcWorld*)h)->world.get(), camera19, width, height, spp, max_depth, seed, rng_mode, rows, n_rows, threads, rgb, accum, stats_out);
+}
+// The same loop with Renderer's other RayTracer, SingleLightSourceRayTracer{light_source, intensity} (raytrace.rs:110-135); light4 = x, y, z, intensity.
+double orc_render_single_light(void* h, const double camera19[19], int width, int height, int spp, const double light4[4], uint64_t seed, int rng_mode,
+                               const int* rows, int n_rows, int threads, int32_t* rgb, double* accum) {
+    return render_world(((OrcWorld*)h)->world.get(), camera19, width, height, spp, 1, seed, rng_mode, rows, n_rows, threads, rgb, accum, nullptr, light4);
+}
+void orc_trace_ray_single_light(void* h, const double o[3], const double d[3], const double light4[4], uint64_t seed, uint32_t pixel, uint32_t sample, double out[3]) {
+    const World& w = *((OrcWorld*)h)->world;
+    PhiloxStream rng(seed, pixel, sample);
+    Color c = trace_single_light(Ray(Point3(o[0], o[1], o[2]), Vec3(d[0], d[1], d[2])), *w.root, w.background, Point3(light4[0], light4[1], light4[2]), light4[3], rng);
+    out[0] = c.e[0]; out[1] = c.e[1]; out[2] = c.e[2];
 }
 // The same render over an arbitrary flattened scene (oracle_scene.cpp, orc_scene_new): the randomised parity tests.
 // background_kind: 0 black, 1 gradient (bottom .. top, raytrace.rs:29-35).

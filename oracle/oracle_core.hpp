@@ -1011,6 +1011,45 @@ inline Color trace_internal(const Ray& ray, const Hittable& world, const Backgro
     return bg.color(ray);
 }
 
+// f64::powi(n), n > 0, as llvm.powi lowers it (compiler-rt __powidf2, and the same product sequence when LLVM expands a constant
+// exponent inline): square-and-multiply from the low bit
+inline double powi_pos(double x, int n) {
+    double a = x, r = 1.0;
+    for (;;) {
+        if (n & 1) r *= a;
+        n /= 2;
+        if (n == 0) break;
+        a *= a;
+    }
+    return r;
+}
+// SingleLightSourceRayTracer::trace (raytrace.rs:110-135): one bounce - the hit's scatter decides between the emitter branch and a
+// Lambert + Blinn-Phong term towards one point light (the scattered ray is dropped, its RNG draws are not).  The reference holds no
+// output of this tracer (it is constructed only in a comment, main.rs:153): parity unpinned beyond this restatement.
+inline Color trace_single_light(const Ray& ray, const Hittable& world, const Background& bg, const Point3& light_source, double intensity, Rng& rng) {
+    g_stats.rays++;
+    Hit hit;
+    if (world.hit(ray, 0.001, INF, rng, hit)) {
+        Color attenuation;
+        Ray scattered;
+        rng.begin_scatter();
+        const bool scatters = hit.material->scatter(ray, hit, rng, attenuation, scattered);
+        rng.end_scatter();
+        if (scatters) {
+            g_stats.scatters++;
+            const Vec3 l = (light_source - hit.p).unit();
+            const Vec3 v = -ray.dir.unit();
+            const Vec3 h = (l + v).unit();
+            // "All materials are Lambertian."
+            const Color lambertian = attenuation * intensity * std::fmax(l.dot(hit.normal), 0.0);
+            const Color blinn_phong = 0.5 * Color(1, 1, 1) * intensity * powi_pos(std::fmax(h.dot(hit.normal), 0.0), 100);
+            return lambertian + blinn_phong;
+        }
+        return hit.material->emit(hit.u, hit.v, hit.p);
+    }
+    return bg.color(ray);
+}
+
 // worlds.rs
 struct WorldCamera { Point3 lookfrom, lookat; double field_of_view; };
 struct PrimRecord {  // registry used by tests to compare against the product's flattened scene

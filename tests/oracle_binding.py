@@ -83,6 +83,34 @@ class OracleWorld:
                             n_rows, threads, rgb.ctypes.data_as(C.c_void_p), accum.ctypes.data_as(C.c_void_p) if want_accum else None, stats)
         return rgb, accum, dict(zip(STAT_NAMES, [int(x) for x in stats])), float(secs)
 
+    def render_single_light(self, camera19, width, height, spp, light_source, intensity, seed=None, rng_mode=RNG_PHILOX_SAMPLE, rows=None, threads=0, want_accum=False):
+        """render() with the Renderer's other RayTracer, SingleLightSourceRayTracer (raytrace.rs:110-135).  Returns (rgb, accum or None)."""
+        L = self.oracle.L
+        rgb = np.zeros((height, width, 3), dtype=np.int32)
+        accum = np.zeros((height, width, 3)) if want_accum else None
+        if rows is None:
+            rows_ptr, n_rows = None, 0
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int32)
+            rows_ptr, n_rows = rows.ctypes.data_as(C.c_void_p), int(rows.size)
+        L.orc_render_single_light.restype = C.c_double
+        L.orc_render_single_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint64, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_render_single_light(self.handle, (C.c_double * 19)(*camera19), width, height, spp, (C.c_double * 4)(*(list(light_source) + [intensity])),
+                                  C.c_uint64(self.seed if seed is None else seed), rng_mode, rows_ptr, n_rows, threads, rgb.ctypes.data_as(C.c_void_p),
+                                  accum.ctypes.data_as(C.c_void_p) if want_accum else None)
+        return rgb, accum
+
+    def trace_ray_single_light(self, origin, direction, light_source, intensity, seed, pixel, sample):
+        """SingleLightSourceRayTracer::trace of one ray with the Philox stream of (pixel, sample) from its first draw."""
+        L = self.oracle.L
+        out = (C.c_double * 3)()
+        L.orc_trace_ray_single_light.restype = None
+        L.orc_trace_ray_single_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        L.orc_trace_ray_single_light(self.handle, (C.c_double * 3)(*origin), (C.c_double * 3)(*direction), (C.c_double * 4)(*(list(light_source) + [intensity])),
+                                     C.c_uint64(seed), pixel, sample, out)
+        return np.array(list(out))
+
     def close(self):
         if self.handle:
             self.oracle.L.orc_world_free(self.handle)

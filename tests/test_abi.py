@@ -34,7 +34,7 @@ def test_struct_sizes_match_the_header(mlrt):
     # natural-alignment sizes of the POD structs in include/mlrt.h
     assert C.sizeof(mlrt.Material) == 40 and C.sizeof(mlrt.Texture) == 48 and C.sizeof(mlrt.Sphere) == 40 and C.sizeof(mlrt.Box) == 56
     assert C.sizeof(mlrt.Rect) == 56 and C.sizeof(mlrt.BvhNode) == 56 and C.sizeof(mlrt.Transform) == 56 and C.sizeof(mlrt.Object) == 32
-    assert C.sizeof(mlrt.CameraStruct) == 152 and C.sizeof(mlrt.Params) == 80
+    assert C.sizeof(mlrt.CameraStruct) == 152 and C.sizeof(mlrt.Params) == 112
 
 
 def test_invalid_scene_is_rejected_before_touching_a_device(mlrt):
