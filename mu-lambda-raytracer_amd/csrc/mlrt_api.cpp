@@ -1575,6 +1575,16 @@ int32_t mlrt_debug_probe_divide(mlrt_context* ctx, int32_t blocks, int32_t per_t
         MLRT_HIP(hipMemcpy(out, d_out, sizeof zero, hipMemcpyDeviceToHost));
     });
 }
+// log_uniform (mlrt_kernel.hip: the logarithm of a medium's draw, volumes.rs:48) of the uniforms (k0 + i) 2^-24, i < n
+int32_t mlrt_debug_probe_log(mlrt_context* ctx, int32_t k0, int32_t n, double* out) {
+    return guarded([&] {
+        MLRT_REQUIRE(ctx && out && n >= 0 && k0 >= 0 && (int64_t)k0 + n <= (1 << 24), "bad argument");
+        DeviceBuffers d;
+        void* d_out = d.alloc((size_t)n * sizeof(double));
+        probe_launch(ctx, 7, 0, n, nullptr, nullptr, d_out, nullptr, k0, [](auto&) {});
+        MLRT_HIP(hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
 int32_t mlrt_debug_probe_to_rgb(mlrt_context* ctx, int32_t spp, int32_t n, const double* radiance, int32_t* rgb) {
     return guarded([&] {
         MLRT_REQUIRE(ctx && radiance && rgb && n >= 0 && spp >= 1, "bad argument");

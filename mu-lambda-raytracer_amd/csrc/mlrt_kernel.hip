@@ -208,8 +208,31 @@ DEV float abs_r(float a) { return fabsf(a); }
 DEV double abs_r(double a) { return fabs(a); }
 DEV float sin_r(float a) { return sinf(a); }
 DEV double sin_r(double a) { return sin(a); }
-DEV float log_r(float a) { return logf(a); }
-DEV double log_r(double a) { return log(a); }
+// ln of a medium's uniform draw (volumes.rs:48, f64 builds): x = 0, or normal and in [2^-32, 1).  The classic argument reduction
+// x = 2^k m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), ln m = 2 atanh(s) = f - f^2/2 + s (f^2/2 + R(s^2)) with R a degree-7
+// minimax polynomial in s^2 (the coefficients of fdlibm's e_log.c; error below 1 ulp), ln 2 added in two parts.  ~40 instructions where
+// the device library's log - double-double arithmetic, correct to the last bit or so - takes ~85: the medium's log is issued in nearly
+// every special batch of a scene with fog.  The oracle calls glibc's log (what Rust's f64::ln calls): either way the last bit may differ,
+// which is what the <= 0.01 % tolerance of the worlds with media is for (tests/test_gpu_parity.py).
+#ifndef MLRT_MEDIUM_LOG_LIBM
+#define MLRT_MEDIUM_LOG_LIBM 0
+#endif
+DEV double log_uniform(double x) {
+    if (MLRT_MEDIUM_LOG_LIBM) return log(x);
+    if (x == 0.0) return -(double)INFINITY;
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
 DEV float floor_r(float a) { return floorf(a); }
 DEV double floor_r(double a) { return floor(a); }
 
@@ -854,7 +877,7 @@ DEV void special_entry(const Scene& S, const DNode<creal>& n, Cursor& c, P3 o, P
                 const double xi = u01d(rng_next(g, key));
                 double density[1];
                 prim_params<1>(S, c.node, n, density);  // neg_inv_density
-                const double hit_distance = density[0] * (kFast ? (double)(__builtin_amdgcn_logf((float)xi) * 0.693147180559945f) : log(xi));  // (v_log_f32 is log2; xi = 0 gives -inf: no hit, as with ln)
+                const double hit_distance = density[0] * (kFast ? (double)(__builtin_amdgcn_logf((float)xi) * 0.693147180559945f) : log_uniform(xi));  // (v_log_f32 is log2; xi = 0 gives -inf: no hit, as with ln)
                 if (!(hit_distance > distance_inside)) {
                     c.closest = kFast ? dfma(hit_distance, inv_ray_scale, t1) : t1 + hit_distance / ray_scale;
                     c.hit_node = c.node; c.hit_aux = 0; c.hit_xf = c.xf;
@@ -2157,6 +2180,11 @@ __global__ void mlrt_probe_turbulence_kernel(const KParams<real> P, int table, i
     const float w = wave_turbulence(S, table, (float)p.x, (float)p.y, (float)p.z, lane);
     if (lane == 0) wave[k] = (double)w;
 }
+// log_uniform of the 24-bit uniforms (k0 + i) 2^-24, i < n: the medium's logarithm over its whole domain
+__global__ void mlrt_probe_log_kernel(int k0, int n, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log_uniform(u01d((uint32_t)(k0 + i) << 8));
+}
 // Texture::value (textures.rs, image_texture.rs) of texture `tex` at (u, v, p)
 __global__ void mlrt_probe_texture_kernel(const KParams<real> P, int tex, int n, const double* uvp, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2328,6 +2356,8 @@ extern "C" int MLRT_CAT(mlrt_probe_launch_, MLRT_SUFFIX)(int kind, const void* k
     } else if (kind == 6) {
         const int* e = static_cast<const int*>(a);  // host pointer: per_thread, seed, divisor exponents lo / hi, numerator exponents lo / hi
         hipLaunchKernelGGL(mlrt_probe_divide_kernel, dim3((unsigned)n), dim3(256), 0, stream, e[0], (uint32_t)e[1], e[2], e[3], e[4], e[5], static_cast<unsigned long long*>(c));
+    } else if (kind == 7) {
+        hipLaunchKernelGGL(mlrt_probe_log_kernel, dim3(grid), dim3(64), 0, stream, iarg, n, static_cast<double*>(c));
     } else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

@@ -258,3 +258,32 @@ def test_quotients_over_a_shared_divisor_are_the_divisions(dbg, build):
         check(m, m.lib().mlrt_debug_probe_divide(ctx, 256, 160, 1000 + seed, a_lo, a_hi, x_lo, x_hi, out))
         assert out[0] == 0, (build, (a_lo, a_hi, x_lo, x_hi), int(out[0]), [hex(int(v)) for v in out[1:]])
     m.lib().mlrt_context_destroy(ctx)
+
+
+@pytest.mark.parametrize("build", ["fp64", "fp64_strict"])
+def test_the_mediums_logarithm_over_all_its_inputs(dbg, build):
+    """log_uniform (mlrt_kernel.hip; ConstantMedium's ln of a uniform, volumes.rs:48) on EVERY input it can get - the 2^24 uniforms
+    k 2^-24 - against glibc's log (what the oracle, and Rust's f64::ln, call): never more than one unit in the last place away, the
+    same double for nine inputs in ten, and -inf at 0 (no hit, as with ln).  The frames of the worlds with media are held to the
+    oracle's with the tolerance this leaves (test_gpu_parity.py)."""
+    m = dbg
+    sc = dc.base(m)
+    sc.add_prim(sc.box((0, 0, 0), (1, 1, 1), sc.lambertian(sc.t_white)))
+    ctx = context(m, sc.to_ctypes(), build)
+    L = m.lib()
+    L.mlrt_debug_probe_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    differ, worst, chunk = 0, 0.0, 1 << 22
+    for k0 in range(0, 1 << 24, chunk):
+        out = np.zeros(chunk)
+        check(m, L.mlrt_debug_probe_log(ctx, k0, chunk, ptr(out)))
+        x = np.arange(k0, k0 + chunk, dtype=np.float64) * 2.0 ** -24
+        if k0 == 0:
+            assert out[0] == -np.inf
+            out, x = out[1:], x[1:]
+        want = np.log(x)
+        bad = out != want
+        differ += int(bad.sum())
+        if bad.any():
+            worst = max(worst, float((np.abs(out[bad] - want[bad]) / np.spacing(np.abs(want[bad]))).max()))
+    assert worst <= 1.0 and differ < 0.10 * (1 << 24), (differ, worst)
+    m.lib().mlrt_context_destroy(ctx)
