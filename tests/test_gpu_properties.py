@@ -101,6 +101,10 @@ def test_bad_arguments_fail_loudly(mlrt):
     params.samples_per_pixel = 4
     with pytest.raises(mlrt.MlrtError):
         mlrt.Renderer(w, cam, params, device=99)
+    # mlrt_device_warm_up: the process's first GPU operation taken out of a caller's timing window (the CLI reports it on its own line)
+    assert mlrt.lib().mlrt_device_warm_up(0) == 0 and mlrt.lib().mlrt_device_warm_up(99) == mlrt.MLRT_ERR_INVALID
+    out = subprocess.run([mlrt.CLI_PATH, "--world=simple", "--seed=1", "--image_width=64", "--samples_per_pixel=1", "--format=p6"], capture_output=True, check=True)
+    assert b"Device ready in" in out.stderr and b"Rendered in" in out.stderr
     r.close()
     w.close()
 
