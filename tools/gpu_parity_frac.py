@@ -16,7 +16,8 @@ from test_gpu_parity import render_both, metrics
 
 oracle = oracle_binding.Oracle()
 earth = pkg.load_earthmap()
-for name, width, aspect, spp in [("cornell_smoke", 160, 1.0, 16), ("final_scene", 200, 1.0, 16), ("cornell_smoke", 300, 1.0, 64), ("final_scene", 300, 1.0, 64)]:
+for name, width, aspect, spp in [("cornell_smoke", 160, 1.0, 16), ("final_scene", 200, 1.0, 16), ("cornell_smoke", 300, 1.0, 64), ("final_scene", 300, 1.0, 64),
+                                 ("random_chk", 300, 1.5, 32), ("two_spheres", 300, 1.5, 32), ("debug_perlin", 300, 1.0, 32), ("simple_light", 300, 1.5, 32)]:
     got, ref, info = render_both(pkg, oracle, name, width, aspect, spp, pkg.PRECISION_FP64, earth=earth if name == "final_scene" else None)
     frac, rmse, maxdiff = metrics(got, ref)
     print("%-14s %4d spp %3d: %d of %d channels differ (%.2e), max |diff| %d, rmse %.2e" % (name, width, spp, int(round(frac * got.size)), got.size, frac, maxdiff, rmse), flush=True)
