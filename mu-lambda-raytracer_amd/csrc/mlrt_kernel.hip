@@ -1094,10 +1094,12 @@ DEV HitAttr hit_attributes(const Scene& S, const Cursor& c, P3 o, P3 d) {
         } else if (FEAT & FEAT_RECT) {
             const int a0 = (n.tag >> 4) & 3, a1 = (n.tag >> 6) & 3, ap = (n.tag >> 8) & 3;
             outward = axis_vec(ap, (real)1);
-            double rv[5];
-            prim_params<5>(S, c.hit_node, n, rv);
-            u = div_r((real)compp(po, a0) - (real)rv[0], (real)rv[1] - (real)rv[0]);
-            v = div_r((real)compp(po, a1) - (real)rv[2], (real)rv[3] - (real)rv[2]);
+            if ((FEAT & (FEAT_TEX_IMAGE | FEAT_TEX_CHECKER)) && (S.materials[mat_id].kind & MATFLAG_NEEDS_UV)) {  // (aarects.rs:56-57; only a texture reads them)
+                double rv[5];
+                prim_params<5>(S, c.hit_node, n, rv);
+                u = div_r((real)compp(po, a0) - (real)rv[0], (real)rv[1] - (real)rv[0]);
+                v = div_r((real)compp(po, a1) - (real)rv[2], (real)rv[3] - (real)rv[2]);
+            }
         }
         front_face = dot(outward, odf) < (real)0;  // Hit::new_with_face_normal, hittable.rs:18-30
         normal = front_face ? outward : -outward;

@@ -16,7 +16,7 @@ def load(path, name):
 
 def main():
     A, B = load(os.path.abspath(sys.argv[1]), "mlrt_a"), load(os.path.abspath(sys.argv[2]), "mlrt_b")
-    cases = [("random", 1200, 1.5, 500), ("final_scene", 800, 1.0, 1000), ("cornell_smoke", 600, 1.0, 200), ("two_spheres", 800, 1.5, 200), ("random_chk", 800, 1.5, 200)]
+    cases = [("random", 1200, 1.5, 500), ("final_scene", 800, 1.0, 1000), ("cornell_smoke", 600, 1.0, 200), ("cornell_box", 600, 1.0, 200), ("simple_light", 800, 1.5, 200), ("two_spheres", 800, 1.5, 200), ("random_chk", 800, 1.5, 200)]
     for name, W, aspect, spp in cases:
         for prec in (1, 0):
             t = {"a": [], "b": []}
