@@ -16,13 +16,13 @@ def load(path, name):
 
 def main():
     A, B = load(os.path.abspath(sys.argv[1]), "mlrt_a"), load(os.path.abspath(sys.argv[2]), "mlrt_b")
-    cases = [("random", 1200, 1.5, 500), ("final_scene", 800, 1.0, 1000), ("cornell_smoke", 600, 1.0, 200), ("cornell_box", 600, 1.0, 200), ("simple_light", 800, 1.5, 200), ("two_spheres", 800, 1.5, 200), ("random_chk", 800, 1.5, 200)]
+    cases = [("random", 1200, 1.5, 500), ("final_scene", 800, 1.0, 1000), ("cornell_smoke", 600, 1.0, 200), ("cornell_box", 600, 1.0, 200), ("simple_light", 800, 1.5, 200), ("two_spheres", 800, 1.5, 200), ("random_chk", 800, 1.5, 200), ("earth", 800, 1.5, 200), ("debug_perlin", 600, 1.0, 200)]
     for name, W, aspect, spp in cases:
         for prec in (1, 0):
             t = {"a": [], "b": []}
             ctx = {}
             for key, m in (("a", A), ("b", B)):
-                earth = m.load_earthmap() if name == "final_scene" else None
+                earth = m.load_earthmap() if name in ("final_scene", "earth") else None
                 w = m.World(name, 42, earth)
                 H = m.image_height(W, aspect)
                 r = m.Renderer(w, m.default_camera(w, aspect), m.make_params(w, W, H, spp), precision=prec)
