@@ -483,6 +483,9 @@ void pack_materials(const mlrt_scene& s, bool solid_only, std::vector<DMaterial<
         if (solid_only && tex >= 0)
             for (int k = 0; k < 3; k++) d.albedo[k] = (M)s.textures[tex].color[k];
         d.param = (M)m.param;
+        // Dielectric (attenuation 1: its albedo is never read): albedo[0] = 1.0 / ir, the refraction ratio of a front-face hit
+        // (materials.rs:92) - the same IEEE division, done here once instead of in every shading batch
+        if (m.kind == MLRT_MAT_DIELECTRIC) d.albedo[0] = (M)1 / (M)m.param;
         out.push_back(d);
     }
 }

@@ -1148,6 +1148,8 @@ DEV bool scatter(const Scene& S, const HitAttr& h, V3 texture_colour, P3& o, P3&
     rng_scatter_words<FEAT>(g, key, bounce, w0, w1, w2);
     V3 s = mk(0, 0, 0);
     if (three) s = unit_ball_from_words(w0, w1, w2);
+    // (measured and not kept: the unit direction and its reflection, which Metal and Dielectric both start from, evaluated once in front of
+    // the two branches - fewer instructions per batch on paper, six more live registers in practice: C2 f64 +2.7 %, f32 +1.9 %)
     if (mk_kind == MLRT_MAT_LAMBERTIAN) {  // materials.rs:25-34 (quirk Q1)
         if (!(dot(normal, s) > (real)0)) s = -s;  // random_in_hemisphere, vec.rs:36-43
         V3 dir = normal + s;
@@ -1169,7 +1171,7 @@ DEV bool scatter(const Scene& S, const HitAttr& h, V3 texture_colour, P3& o, P3&
         return false;
     }
     if (mk_kind == MLRT_MAT_DIELECTRIC) {  // materials.rs:88-106 (quirk Q8)
-        const real refraction_ratio = !front_face ? m.param : div_r((real)1, m.param);
+        const real refraction_ratio = !front_face ? m.param : m.albedo[0];  // 1.0 / ir, divided once by the packer (mlrt_api.cpp pack_materials)
         const V3 unit_direction = unit(dw);
         const real cos_theta = min_r(dot(normal, -unit_direction), (real)1);
         const real sin_theta = sqrt_r((real)1 - cos_theta * cos_theta);
