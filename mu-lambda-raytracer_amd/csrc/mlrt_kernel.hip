@@ -1328,13 +1328,23 @@ DEV unsigned long long to_fixed(float c) {
 #endif
 // Batch thresholds (lanes parked on special entries / on shading before the batch runs), per variant: measured optima
 // (A/B in one process): sphere-only variant 24 / 40 (C2: 45.1 ms at 32 / 32, 43.7 at 24 / 40: its special batch is short,
-// its shading batch long), full variant 32 / 32 (final_scene: 24 / 32 -1.5 %, 32 / 40 and 40 / 32 -5 %).
+// its shading batch long), full variant 32 / 32 (final_scene: 24 / 32 -1.5 %, 32 / 40 and 40 / 32 -5 %).  The smaller feature subsets -
+// every reference world but final_scene - take 40 / 40 (MLRT_T_*_SMALL): cornell_smoke -3 %, random_chk f64 -2.6 %, cornell_box -1.1 %,
+// the others -0.5 %, where final_scene loses 6 % (profiles/r03_ab_instruction_trims.txt).
 #ifndef MLRT_T_SPECIAL
 #define MLRT_T_SPECIAL 32
 #endif
 #ifndef MLRT_T_SHADE
 #define MLRT_T_SHADE 32
 #endif
+#ifndef MLRT_T_SPECIAL_SMALL
+#define MLRT_T_SPECIAL_SMALL 40
+#endif
+#ifndef MLRT_T_SHADE_SMALL
+#define MLRT_T_SHADE_SMALL 40
+#endif
+// (a variant with both media and image textures is final_scene's, or the one with every feature)
+constexpr bool big_world_variant(uint32_t feat) { return (feat & (FEAT_MEDIUM | FEAT_TEX_IMAGE)) == (FEAT_MEDIUM | FEAT_TEX_IMAGE); }
 #ifndef MLRT_T_SPECIAL_LEAN
 #define MLRT_T_SPECIAL_LEAN 24
 #endif
@@ -1761,7 +1771,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_special = __ballot(phase == PH_SPECIAL);
         // (measured and not kept: the batches also run as soon as fewer than 8 / 16 / 24 / 32 lanes still traverse - C2 f64 +1 / +1.5 / +2.3 / +4 %,
         // final_scene f64 +0.6 / +4.7 / +8.5 / +12 %: a batch that runs early runs with fewer lanes, and it is the batches that cost)
-        if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= (FEAT == 0 ? MLRT_T_SPECIAL_LEAN : MLRT_T_SPECIAL) || m_trav == 0ull))) {
+        if (MLRT_RARELY(m_special != 0ull && (__popcll(m_special) >= (FEAT == 0 ? MLRT_T_SPECIAL_LEAN : (big_world_variant(FEAT) ? MLRT_T_SPECIAL : MLRT_T_SPECIAL_SMALL)) || m_trav == 0ull))) {
             if (MLRT_STATS_ON(P)) { st_sb++; st_sl += (unsigned int)__popcll(m_special); st_pspecial += (unsigned int)__popcll(__ballot(phase == PH_SPECIAL && depth == P.max_depth)); }
             if constexpr (PAIR) {
 #pragma unroll
@@ -1812,7 +1822,7 @@ void mlrt_render_kernel(const KParams<real> P) {
         const unsigned long long m_shade = __ballot(phase == PH_SHADE);
         // (the end of the loop, below, decided here where the masks are at hand)
         const bool nobody_runs = (m_trav | m_special | m_shade) == 0ull;
-        const bool batch = m_shade != 0ull && (__popcll(m_shade) >= (FEAT == 0 ? MLRT_T_SHADE_LEAN : MLRT_T_SHADE) || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
+        const bool batch = m_shade != 0ull && (__popcll(m_shade) >= (FEAT == 0 ? MLRT_T_SHADE_LEAN : (big_world_variant(FEAT) ? MLRT_T_SHADE : MLRT_T_SHADE_SMALL)) || (m_trav == 0ull && m_special == 0ull));  // wave-uniform
         if (MLRT_RARELY(batch)) {
             if (MLRT_STATS_ON(P)) { st_hb++; st_hl += (unsigned int)__popcll(m_shade); }
             const bool mine = phase == PH_SHADE;
